@@ -1,0 +1,270 @@
+/*
+ * include/rt_engine.h -- C ABI of the MI355X-native ray-tracing hot path.
+ *
+ * Drop-in boundary for ONE path of leonZtiger/Ray-Tracer-engine: the per-pixel
+ * ray-generation -> sphere-scene intersection -> shading -> framebuffer-write
+ * kernel (`rayTrace`, /root/reference/kernel.cu:1614-1690) together with the
+ * host surface around it (kernel.cuh:3-4, memManager.h:11-18, window.h:7-16,
+ * sprite.h:11-47). Plain C types only: no HIP, torch or C++ types appear in any
+ * signature, so the library can be bound from C, C++, ctypes, cgo, JNI, ...
+ *
+ * Every entry point names the reference interface it replaces (file:line).
+ * Entry points return 0 on success and a non-zero rt_status on failure, unless
+ * they mirror a reference function that is void (those keep the reference's
+ * fatal convention: print, reset the device, exit(99) -- memManager.cpp:3-11).
+ *
+ * Threading: like the reference (single Win32 UI thread) the entry points are
+ * not thread-safe; use one caller thread per process. One process drives one
+ * GPU; multi-GPU runs are one process per GPU.
+ */
+#ifndef RT_ENGINE_H
+#define RT_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+#define RT_MAX_LIGHTS 8      /* reference uses light_size = 3 (kernel.cu:1692) */
+#define RT_MAX_SPP 16
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = 1,      /* bad argument (null pointer, size <= 0, ...)       */
+    RT_ERR_UNSUPPORTED = 2,  /* scene uses a primitive outside the sphere path    */
+    RT_ERR_HIP = 3,          /* a HIP runtime call failed (see rt_last_error())   */
+    RT_ERR_NO_DEVICE = 4,    /* no gfx950 device / kernel image not loadable      */
+    RT_ERR_CAPACITY = 5      /* sphere_count or light_size above the build limit  */
+} rt_status;
+
+/* ------------------------------------------------------------------ *
+ * POD mirrors of the reference's kernel-argument types. Layouts are   *
+ * byte-compatible with the MSVC x64 / nvcc layouts the reference      *
+ * hard-codes (kernel.cu:1214,1219: 40 and 32 bytes).                  *
+ * ------------------------------------------------------------------ */
+typedef struct rt_vec3 { float x, y, z; } rt_vec3;          /* vec3d, kernel.cu:38-40   */
+typedef struct rt_ray { rt_vec3 Org, Dir; } rt_ray;          /* ray,   kernel.cu:225-236 */
+
+typedef struct rt_camera {                                   /* camera, kernel.cu:237-262 */
+    rt_vec3 Org, Dir;
+    float aspect;            /* set per frame (kernel.cu:1773), unused by the kernel */
+    float Camyaw, Campitch;  /* degrees; defaults 180 / -20 (kernel.cu:261)          */
+} rt_camera;                                                 /* 36 bytes */
+
+typedef struct rt_light {                                    /* light, kernel.cu:1246-1261 */
+    rt_vec3 pos;
+    float size, r, g, b;
+} rt_light;                                                  /* 28 bytes */
+
+typedef struct rt_sphere {                                   /* sphere : shape, kernel.cu:265-358 */
+    void *vptr_slot;         /* shape has a virtual method; ignored by this library   */
+    rt_vec3 orgin;           /* (sic) centre                                          */
+    uint8_t reflective;      /* unused by the kernel                                  */
+    uint8_t pad_[3];
+    float radius;            /* holds r*r (ctor, kernel.cu:287); intersect squares it AGAIN (:334) */
+    uint32_t tail_pad_;
+} rt_sphere;                                                 /* 32 bytes */
+
+typedef struct rt_buffer {                                   /* buffer, sprite.h:11-19 */
+    float *data;             /* planar floats in [0,1]                                */
+    int size;                /* bytes (Sprite.cpp:14)                                 */
+} rt_buffer;
+
+typedef struct rt_sprite {                                   /* sprite, sprite.h:25-47 */
+    rt_buffer *rBuff, *gBuff, *bBuff;
+    int width, height;
+} rt_sprite;
+
+typedef struct rt_skybox {                                   /* skybox, kernel.cu:1116-1173 */
+    rt_sphere *box;          /* centre (0,0,0), ctor radius 10000 (kernel.cu:1122,1700) */
+    rt_sprite *skyboxTex;
+} rt_skybox;
+
+typedef struct rt_object {                                   /* object, kernel.cu:1176-1244 (field order kept) */
+    int sphere_count, plane_count, cube_count;               /* :1231 */
+    int depth;                                               /* :1232 */
+    rt_sphere *s1;           /* host staging copy                                     */
+    rt_sphere *d_spheres;    /* what the kernel reads (:1333)                         */
+    void *c1, *d_cubes;      /* cube  -- OUT OF SCOPE: cube_count must be 0            */
+    void *planes, *d_planes; /* plane -- OUT OF SCOPE: plane_count must be 0           */
+    void *mesh1;             /* mesh  -- OUT OF SCOPE: must be NULL (bvhbox_count = 0) */
+    rt_sprite *texture;      /* :1240, read at :1643-1655                             */
+    void *mat;               /* unused                                                */
+    void **tot_mesh;
+    int meshes;
+} rt_object;
+
+/* ------------------------------------------------------------------ *
+ * memManager (memManager.h:11-18, memManager.cpp:3-22)                *
+ * ------------------------------------------------------------------ */
+/* check_cuda(result, func, file, line): on non-zero `err` print
+ * "HIP error = <n> at <file>:<line> '<expr>'", reset the device, exit(99). */
+void rt_check(int err, const char *expr, const char *file, int line);
+/* memManager::operator new : managed allocation + device synchronise. */
+void *rt_managed_alloc(size_t len);
+/* memManager::operator delete : device synchronise + free. */
+void rt_managed_free(void *ptr);
+
+/* ------------------------------------------------------------------ *
+ * Kernel launch (rayTrace<<<blocks,threads>>>, kernel.cu:1615,1780-1783) *
+ * ------------------------------------------------------------------ */
+typedef struct rt_launch_opts {
+    uint32_t struct_size;    /* = sizeof(rt_launch_opts); for ABI growth              */
+    float *rgba;             /* optional device float4 buffer, width*(y1-y0) texels:
+                                linear colour BEFORE the *254 pack        */
+    int y0, y1;              /* row band rendered by this call; 0,0 = whole frame.
+                                `pixels`/`rgba` point at row y0 (band-local buffers)  */
+    int spp;                 /* samples per pixel taken by this call (1..RT_MAX_SPP);
+                                0 = 1. Sample k uses the fixed stratified offset
+                                table (rt_sample_offset); 1 spp = pixel centre, as
+                                the reference (kernel.cu:1624-1625)                   */
+    int sample_base;         /* index of the first sample of this call               */
+    int sample_total;        /* total samples of the frame (divisor at resolve);
+                                0 = spp                                               */
+    int accumulate;          /* 1: add into rgba (progressive); 0: overwrite          */
+    int resolve;             /* 0 default: write packed words when pixels != NULL;
+                                -1: leave `pixels` untouched (intermediate progressive pass) */
+    int cull;                /* -1 default (on); 0 = brute force over the whole list,
+                                exactly the reference's loops; 1 = conservative tile
+                                culling (same output, fewer tests)                    */
+    int tile;                /* 0 default; else tile width in {8,16,32,64} (64 px/wave) */
+    uint64_t *stats;         /* optional device array of RT_STATS_COUNT counters      */
+    int force_slow_path;     /* testing: disable every exactness-preserving shortcut  */
+} rt_launch_opts;
+
+enum { RT_STAT_PRIMARY_TESTS = 0, /* sphere tests issued for primary rays (per lane) */
+       RT_STAT_SHADOW_TESTS = 1,  /* sphere tests issued for shadow rays (per lane)  */
+       RT_STAT_CULL_TESTS = 2,    /* sphere-vs-beam tests (per lane)                 */
+       RT_STAT_HIT_PIXELS = 3,
+       RT_STAT_UNSHADOWED = 4,
+       RT_STAT_WAVE_TEST_SLOTS = 5, /* 64 x wave-level test iterations (issue slots) */
+       RT_STAT_LIST_ENTRIES = 6,  /* sum of survivor-list lengths                     */
+       RT_STAT_LIST_OVERFLOWS = 7,
+       RT_STATS_COUNT = 8 };
+
+/* Same argument order and meaning as the reference kernel; references become
+ * pointers; `stream` is a hipStream_t (NULL = default stream). `pixels` is a
+ * device-accessible buffer of width*height packed 0x00RRGGBB words. objs, lights
+ * and sky are read on the HOST at call time (they live in managed/host memory
+ * in the reference) and mirrored into device-resident tables; texture planes
+ * are uploaded once per (pointer, size) and cached -- call
+ * rt_invalidate_textures() after modifying texel data in place. */
+int rt_launch_raytrace(uint32_t *pixels, int width, int height, float aspect,
+                       const rt_object *objs, const rt_light *lights, int light_size,
+                       rt_camera cam, const rt_skybox *sky, void *stream);
+int rt_launch_raytrace_ex(uint32_t *pixels, int width, int height, float aspect,
+                          const rt_object *objs, const rt_light *lights, int light_size,
+                          rt_camera cam, const rt_skybox *sky, void *stream,
+                          const rt_launch_opts *opts);
+void rt_invalidate_textures(void);
+
+/* ------------------------------------------------------------------ *
+ * Frame driver (kernel.cuh:3-4; kernel.cu:1692-1714, 1762-1792)       *
+ * The C++ symbols `void onStart(); void update();` are exported too.  *
+ * ------------------------------------------------------------------ */
+void rt_on_start(void);      /* builds the default scene (spheres from the MSVC rand()
+                                replay, 3 lights, synthetic textures)                 */
+void rt_update(void);        /* one frame: size query -> launch -> sync -> setPixelBuff */
+/* Scene knobs the reference keeps as compile-time globals (kernel.cu:1231,1695-1702). */
+int rt_config_set_sphere_count(int n);       /* before rt_on_start(); default 1024    */
+int rt_config_set_seed(unsigned int seed);   /* MSVC rand() seed; default 1           */
+rt_camera *rt_config_camera(void);           /* the global `cam` (kernel.cu:1695)     */
+rt_light *rt_config_lights(int *count);      /* the global `lights` (kernel.cu:1694)  */
+float rt_default_aspect(void);               /* (float)tan(90*0.5*3.1415/180), :1701  */
+double rt_last_frame_ms(void);               /* device time of the last rt_update()   */
+
+/* ------------------------------------------------------------------ *
+ * Offscreen stand-in for window.cpp (window.h:7-16). The C++ symbols   *
+ * getScreenWidth/getScreenHeight/setPixelBuff/... are exported (weak)  *
+ * so an application's own window.cpp overrides them.                   *
+ * ------------------------------------------------------------------ */
+int rt_offscreen_resize(int width, int height);   /* WM_SIZE equivalent (window.cpp:29-46),
+                                                      takes the RENDER size directly  */
+const uint32_t *rt_offscreen_pixels(void);        /* render.buffmemory                */
+int rt_offscreen_width(void);
+int rt_offscreen_height(void);
+int rt_offscreen_write_ppm(const char *path);     /* dump the presented frame         */
+
+/* ------------------------------------------------------------------ *
+ * Scene construction helpers (host side, no GPU needed)               *
+ * ------------------------------------------------------------------ */
+/* sphere::sphere(org, r) (kernel.cu:285-288): stores radius = r*r.     */
+void rt_sphere_init(rt_sphere *s, float x, float y, float z, float r);
+/* The scene of object::loadMesh (kernel.cu:1189-1192) with the MSVC rand()
+ * LCG replayed from `seed`; draw order x, y, z, r.      */
+int rt_generate_spheres(rt_sphere *out, int n, unsigned int seed);
+int rt_msvc_rand_sequence(unsigned int seed, int *out, int n);
+/* Deterministic synthetic textures standing in for wood.jpg / sky_box.jpg
+ * (kernel.cu:1700,1706; the assets are not in the reference repo). Planes are
+ * k/255 with integer k, like the 8-bit decode of Sprite.cpp:35-51.
+ * kind 0 = object texture (512x512), kind 1 = sky (2048x1024).           */
+int rt_synth_texture_size(int kind, int *width, int *height);
+int rt_synth_texture(int kind, float *r, float *g, float *b);
+/* sprite(file) without OpenCV: binary PPM (P6) -> planar float planes.    */
+int rt_load_ppm(const char *path, float **r, float **g, float **b, int *width, int *height);
+void rt_free_planes(float *r, float *g, float *b);
+/* Sub-pixel position of sample k of n (n=1 -> 0.5,0.5: the reference).    */
+int rt_sample_offset(int k, int n, double *ox, double *oy);
+
+/* ------------------------------------------------------------------ *
+ * Device-resident frame pipeline (what update() uses internally;      *
+ * exposed so a host can render into its own device buffers, capture   *
+ * the frame into a hipGraph, or render a row band for multi-GPU).     *
+ * ------------------------------------------------------------------ */
+typedef struct rt_scene rt_scene;    /* opaque, device-resident copy of one scene */
+
+rt_scene *rt_scene_create(void);
+void rt_scene_destroy(rt_scene *s);
+int rt_scene_set_spheres(rt_scene *s, const rt_sphere *host_spheres, int n);
+int rt_scene_set_texture(rt_scene *s, const float *r, const float *g, const float *b, int w, int h);
+int rt_scene_set_sky(rt_scene *s, const rt_sphere *box, const float *r, const float *g,
+                     const float *b, int w, int h);
+int rt_scene_set_lights(rt_scene *s, const rt_light *lights, int n);
+
+typedef struct rt_frame_desc {
+    uint32_t struct_size;
+    int width, height;
+    float aspect;
+    rt_camera cam;
+    uint32_t *pixels;        /* device, band-local (row y0 first); may be NULL        */
+    rt_launch_opts opts;     /* rgba / band / spp / cull / stats                       */
+} rt_frame_desc;
+
+int rt_scene_render(rt_scene *s, const rt_frame_desc *fd, void *stream);
+
+/* hipGraph-captured frame loop (config C4): `passes` progressive sample passes
+ * + resolve + optional async copy of the packed frame to pinned host memory,
+ * captured once and replayed per frame.                                        */
+typedef struct rt_frame_graph rt_frame_graph;
+rt_frame_graph *rt_graph_capture(rt_scene *s, const rt_frame_desc *fd, int passes,
+                                 uint32_t *host_pixels /* pinned, may be NULL */, void *stream);
+int rt_graph_launch(rt_frame_graph *g, void *stream);
+int rt_graph_set_camera(rt_frame_graph *g, const rt_camera *cam);
+void rt_graph_destroy(rt_frame_graph *g);
+
+/* ------------------------------------------------------------------ *
+ * Introspection / diagnostics                                         *
+ * ------------------------------------------------------------------ */
+int rt_abi_version(void);
+const char *rt_last_error(void);
+int rt_device_count(void);
+int rt_set_soft_errors(int on);  /* 1: rt_check() records + returns instead of exit(99) */
+/* Device evaluation of the library's scalar building blocks, for bit-for-bit
+ * comparison with the CPU oracle (tests only; all pointers are HOST arrays).
+ * op: 0 cosf, 1 sinf, 2 acosf, 3 atan2f(a,b)                                    */
+int rt_debug_math(int op, const float *a, const float *b, float *out, int n);
+/* sphere::intersect on the device: hit[i], t[i] for rays[i] vs spheres[i].      */
+int rt_debug_intersect(const rt_sphere *spheres, const rt_ray *rays, int n, int *hit, float *t);
+/* The 10 shadow-sample directions of castLightRay (kernel.cu:1442-1468) and its
+ * brightness result for (start, normal, light) against `spheres`.               */
+int rt_debug_light(const rt_sphere *spheres, int n_spheres, const rt_vec3 *start,
+                   const rt_vec3 *normal, const rt_light *light, int n,
+                   float *dirs /* n*30 */, float *brightness /* n */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ENGINE_H */

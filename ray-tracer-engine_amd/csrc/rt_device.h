@@ -1,0 +1,72 @@
+// rt_device.h -- data shared between the host launcher and the gfx950 kernels.
+//
+// Everything that is uniform over a frame is computed ONCE on the host with the
+// same IEEE operations (and the same rt_math.h transcendentals) the reference
+// evaluates per pixel on the device (/root/reference/kernel.cu:248-258,
+// 1454, 1462-1463, 1538, 1629) and handed to the kernel by value, so it sits in
+// SGPRs instead of being recomputed by 64 lanes.
+#pragma once
+#include <stdint.h>
+
+#define RT_DEV_MAX_LIGHTS 8
+#define RT_DEV_MAX_SPP 16
+#define RT_SHADOW_SAMPLES 10   // kernel.cu:1442 `for (int j = 0; j < 10; j++)`
+#define RT_LIST_CAP 256        // survivor-list capacity per wave (float4 entries in LDS)
+#define RT_WAVES_PER_WG 4
+
+// Smallest binary32 >= 0.0001 (binary64): `t >= 0.0001` (kernel.cu:342) compares
+// the widened float with the double literal, which is equivalent to a float
+// compare against this value.
+#define RT_T_MIN 1.00000004749745130538940429688e-4f
+
+struct RtLightDev {
+    float px, py, pz;   // light.pos
+    float size;
+    float r, g, b;
+    float ux, uy, uz;   // pos / |pos| (beam axis for conservative shadow culling)
+    float pos_len;      // |pos|
+    float pad_;
+};
+
+struct RtFrameConsts {
+    // frame / band geometry
+    int width, height;          // full frame (ray generation uses these)
+    int y0, y1;                 // rows rendered by this launch
+    int n_spheres, n_lights;
+    int spp, sample_base;       // samples taken by this launch, index of the first
+    float inv_sample_total_unused_;
+    float sample_total;         // divisor at resolve time, as float
+    int accumulate, resolve;
+    int force_slow;
+    int pad0_;
+
+    // primary-ray uniforms (kernel.cu:1624-1631, 248-258)
+    double aspect_d;            // (double)aspect
+    double width_d, height_d;   // (double)(float)width, (double)(float)height
+    double hw_d;                // (double)((float)height / width)
+    float eye_nz;               // -( -1/aspect ) : z component of (dir - eyePos)
+    float org_x, org_y, org_z;  // eyePos + cam.Org
+    float cos_pitch, sin_pitch, cos_yaw, sin_yaw;
+    double off_x[RT_DEV_MAX_SPP], off_y[RT_DEV_MAX_SPP];
+
+    // shadow-sample uniforms (kernel.cu:1453-1454, 1462-1463, 1538)
+    float jf[RT_SHADOW_SAMPLES];      // (float)j / 10
+    float jcos[RT_SHADOW_SAMPLES];    // cosf(phi_j), phi_j = (float)j/10 * 2.f * 3.1415f
+    float jsin[RT_SHADOW_SAMPLES];    // sinf(phi_j)
+    float btab[RT_SHADOW_SAMPLES + 1];// b after n `b += 0.1` steps (float += double)
+    float pad1_;
+
+    RtLightDev lights[RT_DEV_MAX_LIGHTS];
+
+    // object texture (sprite planes) and sky
+    const float *tex_r, *tex_g, *tex_b;
+    int tex_w, tex_h;
+    const float *sky_r, *sky_g, *sky_b;
+    int sky_w, sky_h;
+    float sky_cx, sky_cy, sky_cz, sky_r2;   // skybox sphere centre, radius*radius
+
+    // outputs
+    float *rgba;                // float4 per pixel, band-local, may be null
+    uint32_t *packed;           // 0x00RRGGBB per pixel, band-local, may be null
+    unsigned long long *stats;  // RT_STATS_COUNT counters, may be null
+};

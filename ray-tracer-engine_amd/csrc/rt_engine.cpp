@@ -1,0 +1,597 @@
+// rt_engine.cpp -- host side of the C ABI (include/rt_engine.h): device-resident
+// scene, frame-uniform hoisting, kernel launch, the rayTrace launch shim and the
+// memManager surface.
+//
+// Reference interfaces replaced here:
+//   memManager / check_cuda      /root/reference/memManager.h:11-18, memManager.cpp:3-22
+//   rayTrace<<<...>>> launch     /root/reference/kernel.cu:1615, 1780-1783
+//   object / sprite / skybox     /root/reference/kernel.cu:1116-1244, sprite.h:11-47
+//
+// There is no CPU fallback: every render entry point needs a gfx950 device and
+// fails with RT_ERR_NO_DEVICE / RT_ERR_HIP otherwise.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rt_engine.h"
+#include "rt_device.h"
+#include "rt_internal.h"
+#include "rt_math.h"
+
+// launchers defined in rt_kernels.hip
+extern "C" hipError_t rt_dev_launch_trace(const RtFrameConsts *fc, const float4 *spheres, int tile_w,
+                                          int cull, int stats, hipStream_t stream);
+extern "C" hipError_t rt_dev_launch_dbg_math(int op, const float *a, const float *b, float *out, int n,
+                                             hipStream_t stream);
+extern "C" hipError_t rt_dev_launch_dbg_intersect(const float4 *tab, const float *rays, int n, int *hit,
+                                                  float *t, hipStream_t stream);
+extern "C" hipError_t rt_dev_launch_dbg_light(const RtFrameConsts *fc, const float4 *tab, const float *starts,
+                                              const float *normals, int light_index, int n, float *dirs,
+                                              float *bright, hipStream_t stream);
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static char g_last_error[512] = "";
+static int g_soft_errors = 0;
+
+void rt_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof g_last_error, fmt, ap);
+    va_end(ap);
+}
+
+int rt_hip_fail(hipError_t e, const char *expr, const char *file, int line)
+{
+    rt_set_error("HIP error = %u (%s) at %s:%d '%s'", (unsigned)e, hipGetErrorString(e), file, line, expr);
+    (void)hipGetLastError();   // clear the sticky error so later calls can proceed
+    return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? RT_ERR_NO_DEVICE : RT_ERR_HIP;
+}
+
+extern "C" const char *rt_last_error(void) { return g_last_error; }
+extern "C" int rt_abi_version(void) { return RT_ABI_VERSION; }
+extern "C" int rt_set_soft_errors(int on)
+{
+    const int old = g_soft_errors;
+    g_soft_errors = on ? 1 : 0;
+    return old;
+}
+extern "C" int rt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+// check_cuda, memManager.cpp:3-11
+extern "C" void rt_check(int err, const char *expr, const char *file, int line)
+{
+    if (err) {
+        fprintf(stderr, "HIP error = %u at %s:%d '%s' \n", (unsigned)err, file, line, expr);
+        rt_set_error("HIP error = %u at %s:%d '%s'", (unsigned)err, file, line, expr);
+        if (g_soft_errors) return;
+        (void)hipDeviceReset();
+        exit(99);
+    }
+}
+#define checkHipErrors(val) rt_check((int)(val), #val, __FILE__, __LINE__)
+
+// memManager::operator new / delete, memManager.cpp:12-22
+extern "C" void *rt_managed_alloc(size_t len)
+{
+    void *ptr = nullptr;
+    checkHipErrors(hipMallocManaged(&ptr, len ? len : 1));
+    checkHipErrors(hipDeviceSynchronize());
+    return ptr;
+}
+extern "C" void rt_managed_free(void *ptr)
+{
+    if (!ptr) return;
+    checkHipErrors(hipDeviceSynchronize());
+    (void)hipFree(ptr);
+}
+
+// ---------------------------------------------------------------------------
+// device-resident scene
+// ---------------------------------------------------------------------------
+struct rt_scene {
+    float4 *d_spheres = nullptr;
+    int n_spheres = 0, cap_spheres = 0;
+    float4 *h_stage = nullptr;   // pinned staging for asynchronous re-uploads
+    int cap_stage = 0;
+    float *d_tex[3] = {nullptr, nullptr, nullptr};
+    int tex_w = 0, tex_h = 0;
+    float *d_sky[3] = {nullptr, nullptr, nullptr};
+    int sky_w = 0, sky_h = 0;
+    float sky_c[3] = {0, 0, 0};
+    float sky_radius = 0;        // the sphere's `radius` field (already r*r)
+    bool have_sky = false;
+    rt_light lights[RT_MAX_LIGHTS];
+    int n_lights = 0;
+};
+
+static const int kMaxSpheresLds = (160 * 1024 - RT_WAVES_PER_WG * RT_LIST_CAP * 16) / 16;
+
+extern "C" rt_scene *rt_scene_create(void) { return new rt_scene(); }
+
+static void free_planes(float *p[3])
+{
+    for (int i = 0; i < 3; ++i) {
+        if (p[i]) (void)hipFree(p[i]);
+        p[i] = nullptr;
+    }
+}
+
+extern "C" void rt_scene_destroy(rt_scene *s)
+{
+    if (!s) return;
+    if (s->d_spheres) (void)hipFree(s->d_spheres);
+    if (s->h_stage) (void)hipHostFree(s->h_stage);
+    free_planes(s->d_tex);
+    free_planes(s->d_sky);
+    delete s;
+}
+
+// {cx, cy, cz, radius*radius}: the only four numbers sphere::intersect reads
+// (kernel.cu:332-334); radius*radius is the same binary32 product either way.
+static void pack_spheres(const rt_sphere *src, int n, float4 *dst)
+{
+    for (int i = 0; i < n; ++i)
+        dst[i] = make_float4(src[i].orgin.x, src[i].orgin.y, src[i].orgin.z, src[i].radius * src[i].radius);
+}
+
+int rt_scene_set_spheres_async(rt_scene *s, const rt_sphere *host_spheres, int n, hipStream_t stream)
+{
+    if (!s || n < 0 || (n > 0 && !host_spheres)) {
+        rt_set_error("rt_scene_set_spheres: invalid argument");
+        return RT_ERR_INVALID;
+    }
+    if (n > kMaxSpheresLds) {
+        rt_set_error("rt_scene_set_spheres: %d spheres exceed the LDS-staged limit of %d", n, kMaxSpheresLds);
+        return RT_ERR_CAPACITY;
+    }
+    if (n > s->cap_spheres) {
+        if (s->d_spheres) RT_HIP(hipFree(s->d_spheres));
+        s->d_spheres = nullptr;
+        s->cap_spheres = 0;
+        RT_HIP(hipMalloc((void **)&s->d_spheres, sizeof(float4) * (size_t)n));
+        s->cap_spheres = n;
+    }
+    if (n > s->cap_stage) {
+        if (s->h_stage) RT_HIP(hipHostFree(s->h_stage));
+        s->h_stage = nullptr;
+        s->cap_stage = 0;
+        RT_HIP(hipHostMalloc((void **)&s->h_stage, sizeof(float4) * (size_t)n, hipHostMallocDefault));
+        s->cap_stage = n;
+    }
+    if (n > 0) {
+        pack_spheres(host_spheres, n, s->h_stage);
+        RT_HIP(hipMemcpyAsync(s->d_spheres, s->h_stage, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, stream));
+    }
+    s->n_spheres = n;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_set_spheres(rt_scene *s, const rt_sphere *host_spheres, int n)
+{
+    const int rc = rt_scene_set_spheres_async(s, host_spheres, n, nullptr);
+    if (rc != RT_OK) return rc;
+    RT_HIP(hipStreamSynchronize(nullptr));
+    return RT_OK;
+}
+
+static int upload_planes(float *dst[3], const float *r, const float *g, const float *b, int w, int h)
+{
+    const float *src[3] = {r, g, b};
+    const size_t bytes = sizeof(float) * (size_t)w * (size_t)h;
+    free_planes(dst);
+    for (int i = 0; i < 3; ++i) {
+        RT_HIP(hipMalloc((void **)&dst[i], bytes));
+        RT_HIP(hipMemcpy(dst[i], src[i], bytes, hipMemcpyDefault));
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_scene_set_texture(rt_scene *s, const float *r, const float *g, const float *b, int w, int h)
+{
+    if (!s || !r || !g || !b || w <= 0 || h <= 0) {
+        rt_set_error("rt_scene_set_texture: invalid argument");
+        return RT_ERR_INVALID;
+    }
+    const int rc = upload_planes(s->d_tex, r, g, b, w, h);
+    if (rc != RT_OK) return rc;
+    s->tex_w = w;
+    s->tex_h = h;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_set_sky(rt_scene *s, const rt_sphere *box, const float *r, const float *g,
+                                const float *b, int w, int h)
+{
+    if (!s || !box || !r || !g || !b || w <= 0 || h <= 0) {
+        rt_set_error("rt_scene_set_sky: invalid argument");
+        return RT_ERR_INVALID;
+    }
+    const int rc = upload_planes(s->d_sky, r, g, b, w, h);
+    if (rc != RT_OK) return rc;
+    s->sky_w = w;
+    s->sky_h = h;
+    s->sky_c[0] = box->orgin.x;
+    s->sky_c[1] = box->orgin.y;
+    s->sky_c[2] = box->orgin.z;
+    s->sky_radius = box->radius;
+    s->have_sky = true;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_set_lights(rt_scene *s, const rt_light *lights, int n)
+{
+    if (!s || n < 0 || (n > 0 && !lights)) {
+        rt_set_error("rt_scene_set_lights: invalid argument");
+        return RT_ERR_INVALID;
+    }
+    if (n > RT_MAX_LIGHTS) {
+        rt_set_error("rt_scene_set_lights: light_size %d > RT_MAX_LIGHTS %d", n, RT_MAX_LIGHTS);
+        return RT_ERR_CAPACITY;
+    }
+    for (int i = 0; i < n; ++i) s->lights[i] = lights[i];
+    s->n_lights = n;
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// sample positions (build-defined extension; n = 1 is the reference's +0.5)
+// ---------------------------------------------------------------------------
+extern "C" int rt_sample_offset(int k, int n, double *ox, double *oy)
+{
+    if (n < 1 || k < 0 || k >= n || !ox || !oy) return RT_ERR_INVALID;
+    int g = 1;
+    while (g * g < n) ++g;   // stratified g x g grid, cell centres
+    *ox = ((double)(k % g) + 0.5) / (double)g;
+    *oy = ((double)(k / g) + 0.5) / (double)g;
+    return RT_OK;
+}
+
+extern "C" float rt_default_aspect(void)
+{
+    return (float)std::tan((90 * 0.5 * 3.1415) / 180);   // kernel.cu:1701
+}
+
+// ---------------------------------------------------------------------------
+// frame uniforms: everything the reference recomputes per pixel from
+// frame-constant inputs, evaluated once with the same operations.
+// ---------------------------------------------------------------------------
+int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameConsts *fc)
+{
+    if (!s || !fd) {
+        rt_set_error("rt_scene_render: null scene or frame");
+        return RT_ERR_INVALID;
+    }
+    if (fd->width <= 0 || fd->height <= 0) {
+        rt_set_error("rt_scene_render: width/height must be positive (%d x %d)", fd->width, fd->height);
+        return RT_ERR_INVALID;
+    }
+    const rt_launch_opts &o = fd->opts;
+    int y0 = o.y0, y1 = o.y1;
+    if (y0 == 0 && y1 == 0) y1 = fd->height;
+    if (y0 < 0 || y1 > fd->height || y0 >= y1) {
+        rt_set_error("rt_scene_render: bad row band [%d,%d) for height %d", y0, y1, fd->height);
+        return RT_ERR_INVALID;
+    }
+    const int spp = o.spp > 0 ? o.spp : 1;
+    const int total = o.sample_total > 0 ? o.sample_total : spp;
+    if (spp > RT_MAX_SPP || total > RT_MAX_SPP || o.sample_base < 0 || o.sample_base + spp > total) {
+        rt_set_error("rt_scene_render: bad sample range base=%d spp=%d total=%d (max %d)", o.sample_base, spp,
+                     total, RT_MAX_SPP);
+        return RT_ERR_INVALID;
+    }
+    if (s->n_spheres > 0 && (!s->d_tex[0] || s->tex_w <= 0)) {
+        rt_set_error("rt_scene_render: scene has spheres but no object texture");
+        return RT_ERR_INVALID;
+    }
+    if (!s->have_sky) {
+        rt_set_error("rt_scene_render: scene has no skybox");
+        return RT_ERR_INVALID;
+    }
+    if (!fd->pixels && !o.rgba) {
+        rt_set_error("rt_scene_render: no output buffer (pixels and opts.rgba are both null)");
+        return RT_ERR_INVALID;
+    }
+
+    memset(fc, 0, sizeof *fc);
+    fc->width = fd->width;
+    fc->height = fd->height;
+    fc->y0 = y0;
+    fc->y1 = y1;
+    fc->n_spheres = s->n_spheres;
+    fc->n_lights = s->n_lights;
+    fc->spp = spp;
+    fc->sample_base = o.sample_base;
+    fc->sample_total = (float)total;
+    fc->accumulate = o.accumulate ? 1 : 0;
+    fc->resolve = (fd->pixels && o.resolve >= 0) ? 1 : 0;
+    fc->force_slow = o.force_slow_path ? 1 : 0;
+
+    // kernel.cu:1624-1625
+    const float aspect = fd->aspect;
+    fc->aspect_d = (double)aspect;
+    fc->width_d = (double)(float)fd->width;
+    fc->height_d = (double)(float)fd->height;
+    fc->hw_d = (double)((float)fd->height / (float)fd->width);
+    // kernel.cu:1629-1631: eyePos = (0,0,-1/aspect); dir - eyePos; eyePos + cam.Org
+    const float ez = -1.f / aspect;
+    fc->eye_nz = 0.f - ez;
+    fc->org_x = 0.f + fd->cam.Org.x;
+    fc->org_y = 0.f + fd->cam.Org.y;
+    fc->org_z = ez + fd->cam.Org.z;
+    // camera::rotateDir, kernel.cu:249-250
+    const float yawRad = (float)(fd->cam.Camyaw * (3.1415 / 180));
+    const float pitchRad = (float)(fd->cam.Campitch * (3.1415 / 180));
+    fc->cos_pitch = rtm::cosf_rt(pitchRad);
+    fc->sin_pitch = rtm::sinf_rt(pitchRad);
+    fc->cos_yaw = rtm::cosf_rt(yawRad);
+    fc->sin_yaw = rtm::sinf_rt(yawRad);
+    for (int k = 0; k < total; ++k) rt_sample_offset(k, total, &fc->off_x[k], &fc->off_y[k]);
+
+    // castLightRay sample constants, kernel.cu:1453-1454, 1462-1463, 1538
+    float b = 0;
+    for (int j = 0; j <= RT_SHADOW_SAMPLES; ++j) {
+        fc->btab[j] = b;
+        b = (float)(b + 0.1);
+    }
+    for (int j = 0; j < RT_SHADOW_SAMPLES; ++j) {
+        const float jf = (float)j / 10;
+        const float phi = jf * 2.f * 3.1415f;
+        fc->jf[j] = jf;
+        fc->jcos[j] = rtm::cosf_rt(phi);
+        fc->jsin[j] = rtm::sinf_rt(phi);
+    }
+    for (int i = 0; i < s->n_lights; ++i) {
+        const rt_light &l = s->lights[i];
+        RtLightDev &d = fc->lights[i];
+        d.px = l.pos.x; d.py = l.pos.y; d.pz = l.pos.z;
+        d.size = l.size;
+        d.r = l.r; d.g = l.g; d.b = l.b;
+        const float len = std::sqrt(l.pos.x * l.pos.x + l.pos.y * l.pos.y + l.pos.z * l.pos.z);
+        d.pos_len = len;
+        // a light at the origin has no beam axis: NaN makes the kernel skip culling
+        d.ux = len > 0 ? l.pos.x / len : NAN;
+        d.uy = len > 0 ? l.pos.y / len : NAN;
+        d.uz = len > 0 ? l.pos.z / len : NAN;
+    }
+    fc->tex_r = s->d_tex[0]; fc->tex_g = s->d_tex[1]; fc->tex_b = s->d_tex[2];
+    fc->tex_w = s->tex_w; fc->tex_h = s->tex_h;
+    fc->sky_r = s->d_sky[0]; fc->sky_g = s->d_sky[1]; fc->sky_b = s->d_sky[2];
+    fc->sky_w = s->sky_w; fc->sky_h = s->sky_h;
+    fc->sky_cx = s->sky_c[0]; fc->sky_cy = s->sky_c[1]; fc->sky_cz = s->sky_c[2];
+    fc->sky_r2 = s->sky_radius * s->sky_radius;
+    fc->rgba = o.rgba;
+    fc->packed = fd->pixels;
+    fc->stats = (unsigned long long *)o.stats;
+    return RT_OK;
+}
+
+static int tile_from_opts(const rt_launch_opts &o, int *tile)
+{
+    const int t = o.tile ? o.tile : 8;
+    if (t != 8 && t != 16 && t != 32 && t != 64) {
+        rt_set_error("rt_scene_render: tile width %d not in {8,16,32,64}", t);
+        return RT_ERR_INVALID;
+    }
+    *tile = t;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_render(rt_scene *s, const rt_frame_desc *fd, void *stream)
+{
+    RtFrameConsts fc;
+    int rc = rt_build_frame_consts(s, fd, &fc);
+    if (rc != RT_OK) return rc;
+    int tile = 8;
+    rc = tile_from_opts(fd->opts, &tile);
+    if (rc != RT_OK) return rc;
+    const int cull = (fd->opts.cull == 0) ? 0 : 1;
+    const int stats = fd->opts.stats ? 1 : 0;
+    RT_HIP(rt_dev_launch_trace(&fc, s->d_spheres, tile, cull, stats, (hipStream_t)stream));
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// rayTrace launch shim (kernel.cu:1615, 1780-1783): same argument list, the
+// object / skybox graphs are read on the host and mirrored to the device.
+// ---------------------------------------------------------------------------
+struct ShimCache {
+    rt_scene *scene = nullptr;
+    const float *tex_key[3] = {nullptr, nullptr, nullptr};
+    int tex_w = 0, tex_h = 0;
+    const float *sky_key[3] = {nullptr, nullptr, nullptr};
+    int sky_w = 0, sky_h = 0;
+    float sky_c[3] = {0, 0, 0};
+    float sky_radius = -1;
+};
+static ShimCache g_shim;
+
+extern "C" void rt_invalidate_textures(void)
+{
+    g_shim.tex_key[0] = g_shim.tex_key[1] = g_shim.tex_key[2] = nullptr;
+    g_shim.sky_key[0] = g_shim.sky_key[1] = g_shim.sky_key[2] = nullptr;
+}
+
+static bool sprite_ok(const rt_sprite *t)
+{
+    return t && t->rBuff && t->gBuff && t->bBuff && t->rBuff->data && t->gBuff->data && t->bBuff->data &&
+           t->width > 0 && t->height > 0;
+}
+
+extern "C" int rt_launch_raytrace_ex(uint32_t *pixels, int width, int height, float aspect,
+                                     const rt_object *objs, const rt_light *lights, int light_size,
+                                     rt_camera cam, const rt_skybox *sky, void *stream,
+                                     const rt_launch_opts *opts)
+{
+    if (!objs || !sky || (!lights && light_size > 0)) {
+        rt_set_error("rt_launch_raytrace: null objs/lights/sky");
+        return RT_ERR_INVALID;
+    }
+    // Out-of-scope primitives: the sphere path only.
+    if (objs->cube_count != 0 || objs->plane_count != 0 || objs->mesh1 != nullptr) {
+        rt_set_error("rt_launch_raytrace: cubes/planes/meshes are outside this library's path "
+                     "(cube_count=%d plane_count=%d mesh1=%p)", objs->cube_count, objs->plane_count, objs->mesh1);
+        return RT_ERR_UNSUPPORTED;
+    }
+    if (objs->sphere_count < 0 || (objs->sphere_count > 0 && !objs->d_spheres)) {
+        rt_set_error("rt_launch_raytrace: bad sphere list");
+        return RT_ERR_INVALID;
+    }
+    if (!sky->box || !sprite_ok(sky->skyboxTex)) {
+        rt_set_error("rt_launch_raytrace: skybox needs a box sphere and a texture");
+        return RT_ERR_INVALID;
+    }
+    if (objs->sphere_count > 0 && !sprite_ok(objs->texture)) {
+        rt_set_error("rt_launch_raytrace: object texture missing");
+        return RT_ERR_INVALID;
+    }
+    if (!g_shim.scene) g_shim.scene = rt_scene_create();
+    rt_scene *s = g_shim.scene;
+    int rc;
+    // textures: uploaded once per (planes, size); see rt_invalidate_textures()
+    if (objs->sphere_count > 0) {
+        const rt_sprite *t = objs->texture;
+        if (t->rBuff->data != g_shim.tex_key[0] || t->gBuff->data != g_shim.tex_key[1] ||
+            t->bBuff->data != g_shim.tex_key[2] || t->width != g_shim.tex_w || t->height != g_shim.tex_h) {
+            rc = rt_scene_set_texture(s, t->rBuff->data, t->gBuff->data, t->bBuff->data, t->width, t->height);
+            if (rc != RT_OK) return rc;
+            g_shim.tex_key[0] = t->rBuff->data; g_shim.tex_key[1] = t->gBuff->data; g_shim.tex_key[2] = t->bBuff->data;
+            g_shim.tex_w = t->width; g_shim.tex_h = t->height;
+        }
+    }
+    {
+        const rt_sprite *t = sky->skyboxTex;
+        if (t->rBuff->data != g_shim.sky_key[0] || t->gBuff->data != g_shim.sky_key[1] ||
+            t->bBuff->data != g_shim.sky_key[2] || t->width != g_shim.sky_w || t->height != g_shim.sky_h ||
+            sky->box->orgin.x != g_shim.sky_c[0] || sky->box->orgin.y != g_shim.sky_c[1] ||
+            sky->box->orgin.z != g_shim.sky_c[2] || sky->box->radius != g_shim.sky_radius) {
+            rc = rt_scene_set_sky(s, sky->box, t->rBuff->data, t->gBuff->data, t->bBuff->data, t->width, t->height);
+            if (rc != RT_OK) return rc;
+            g_shim.sky_key[0] = t->rBuff->data; g_shim.sky_key[1] = t->gBuff->data; g_shim.sky_key[2] = t->bBuff->data;
+            g_shim.sky_w = t->width; g_shim.sky_h = t->height;
+            g_shim.sky_c[0] = sky->box->orgin.x; g_shim.sky_c[1] = sky->box->orgin.y; g_shim.sky_c[2] = sky->box->orgin.z;
+            g_shim.sky_radius = sky->box->radius;
+        }
+    }
+    // spheres and lights are small and may change every frame: re-mirror them
+    rc = rt_scene_set_spheres_async(s, objs->d_spheres, objs->sphere_count, (hipStream_t)stream);
+    if (rc != RT_OK) return rc;
+    rc = rt_scene_set_lights(s, lights, light_size);
+    if (rc != RT_OK) return rc;
+
+    rt_frame_desc fd;
+    memset(&fd, 0, sizeof fd);
+    fd.struct_size = sizeof fd;
+    fd.width = width;
+    fd.height = height;
+    fd.aspect = aspect;
+    fd.cam = cam;
+    fd.pixels = pixels;
+    if (opts) {
+        const size_t nbytes = opts->struct_size < sizeof fd.opts ? opts->struct_size : sizeof fd.opts;
+        memcpy(&fd.opts, opts, nbytes);
+        fd.opts.struct_size = (uint32_t)sizeof fd.opts;
+    } else {
+        fd.opts.cull = -1;
+    }
+    return rt_scene_render(s, &fd, stream);
+}
+
+extern "C" int rt_launch_raytrace(uint32_t *pixels, int width, int height, float aspect,
+                                  const rt_object *objs, const rt_light *lights, int light_size,
+                                  rt_camera cam, const rt_skybox *sky, void *stream)
+{
+    return rt_launch_raytrace_ex(pixels, width, height, aspect, objs, lights, light_size, cam, sky, stream, nullptr);
+}
+
+// ---------------------------------------------------------------------------
+// diagnostics: device evaluation of scalar building blocks (host arrays in/out)
+// ---------------------------------------------------------------------------
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { RT_HIP(hipMalloc((void **)&p, sizeof(T) * (n ? n : 1))); return RT_OK; }
+};
+
+extern "C" int rt_debug_math(int op, const float *a, const float *b, float *out, int n)
+{
+    if (n <= 0 || !a || !out || op < 0 || op > 3 || (op == 3 && !b)) return RT_ERR_INVALID;
+    DevBuf<float> da, db, dout;
+    int rc;
+    if ((rc = da.alloc(n)) || (rc = db.alloc(n)) || (rc = dout.alloc(n))) return rc;
+    RT_HIP(hipMemcpy(da.p, a, sizeof(float) * n, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(db.p, b ? b : a, sizeof(float) * n, hipMemcpyHostToDevice));
+    RT_HIP(rt_dev_launch_dbg_math(op, da.p, db.p, dout.p, n, nullptr));
+    RT_HIP(hipMemcpy(out, dout.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_debug_intersect(const rt_sphere *spheres, const rt_ray *rays, int n, int *hit, float *t)
+{
+    if (n <= 0 || !spheres || !rays || !hit || !t) return RT_ERR_INVALID;
+    std::vector<float4> tab(n);
+    pack_spheres(spheres, n, tab.data());
+    DevBuf<float4> dtab;
+    DevBuf<float> drays, dt;
+    DevBuf<int> dhit;
+    int rc;
+    if ((rc = dtab.alloc(n)) || (rc = drays.alloc(6 * (size_t)n)) || (rc = dt.alloc(n)) || (rc = dhit.alloc(n)))
+        return rc;
+    RT_HIP(hipMemcpy(dtab.p, tab.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(drays.p, rays, sizeof(float) * 6 * n, hipMemcpyHostToDevice));
+    RT_HIP(rt_dev_launch_dbg_intersect(dtab.p, drays.p, n, dhit.p, dt.p, nullptr));
+    RT_HIP(hipMemcpy(hit, dhit.p, sizeof(int) * n, hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(t, dt.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_debug_light(const rt_sphere *spheres, int n_spheres, const rt_vec3 *start,
+                              const rt_vec3 *normal, const rt_light *light, int n, float *dirs,
+                              float *brightness)
+{
+    if (n <= 0 || n_spheres < 0 || !start || !normal || !light || !dirs || !brightness) return RT_ERR_INVALID;
+    rt_scene sc;
+    sc.lights[0] = *light;
+    sc.n_lights = 1;
+    sc.have_sky = true;
+    rt_frame_desc fd;
+    memset(&fd, 0, sizeof fd);
+    fd.width = fd.height = 1;
+    fd.aspect = 1.f;
+    uint32_t dummy;
+    fd.pixels = &dummy;
+    RtFrameConsts fc;
+    int rc = rt_build_frame_consts(&sc, &fd, &fc);
+    if (rc != RT_OK) return rc;
+    fc.n_spheres = n_spheres;
+    std::vector<float4> tab(n_spheres ? n_spheres : 1);
+    if (n_spheres) pack_spheres(spheres, n_spheres, tab.data());
+    DevBuf<float4> dtab;
+    DevBuf<float> dstart, dnormal, ddirs, dbright;
+    if ((rc = dtab.alloc(tab.size())) || (rc = dstart.alloc(3 * (size_t)n)) || (rc = dnormal.alloc(3 * (size_t)n)) ||
+        (rc = ddirs.alloc(30 * (size_t)n)) || (rc = dbright.alloc(n)))
+        return rc;
+    RT_HIP(hipMemcpy(dtab.p, tab.data(), sizeof(float4) * tab.size(), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(dstart.p, start, sizeof(float) * 3 * n, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(dnormal.p, normal, sizeof(float) * 3 * n, hipMemcpyHostToDevice));
+    RT_HIP(rt_dev_launch_dbg_light(&fc, dtab.p, dstart.p, dnormal.p, 0, n, ddirs.p, dbright.p, nullptr));
+    RT_HIP(hipMemcpy(dirs, ddirs.p, sizeof(float) * 30 * n, hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(brightness, dbright.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return RT_OK;
+}

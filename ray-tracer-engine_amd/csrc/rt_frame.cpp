@@ -1,0 +1,203 @@
+// rt_frame.cpp -- frame driver: the host mirror of the reference's
+// `onStart()` / `update()` pair and the globals around them
+// (/root/reference/kernel.cuh:3-4, kernel.cu:1692-1714, 1762-1792), plus the
+// memManager-derived texture classes (sprite.h:11-47, Sprite.cpp:13-65).
+//
+// What changed relative to the reference's update(): the framebuffer and the
+// pinned present staging are allocated once per resolution instead of
+// malloc/free every frame (kernel.cu:1775-1776, 1789-1790), the kernel writes
+// device memory and the frame reaches setPixelBuff() through one asynchronous
+// D2H copy instead of managed-page migration (kernel.cu:1788), and the lights
+// travel as kernel arguments instead of a per-frame cudaMalloc+cudaMemcpy
+// (kernel.cu:1776-1778). Behaviour at the boundary is unchanged: update()
+// returns after the frame has been handed to setPixelBuff().
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../include/rt_engine.h"
+#include "../../include/rt_kernel.h"
+#include "../../include/rt_memmanager.h"
+#include "../../include/rt_window.h"
+#include "rt_internal.h"
+
+// ---- buffer / sprite (Sprite.cpp:13-52) ----
+buffer::buffer(float *pixels, int length)
+{
+    size = length * (int)sizeof(float);
+    data = (float *)rt_managed_alloc((size_t)size);
+    if (data && pixels) memcpy(data, pixels, (size_t)size);
+}
+
+sprite::sprite(std::string file)
+{
+    rBuff = gBuff = bBuff = nullptr;
+    width = height = 0;
+    float *r = nullptr, *g = nullptr, *b = nullptr;
+    int kind = -1;
+    if (file == "synthetic:object") kind = 0;
+    if (file == "synthetic:sky") kind = 1;
+    if (kind >= 0) {
+        rt_synth_texture_size(kind, &width, &height);
+        const size_t n = (size_t)width * height;
+        r = (float *)malloc(n * sizeof(float));
+        g = (float *)malloc(n * sizeof(float));
+        b = (float *)malloc(n * sizeof(float));
+        rt_synth_texture(kind, r, g, b);
+    } else if (rt_load_ppm(file.c_str(), &r, &g, &b, &width, &height) != RT_OK) {
+        fprintf(stderr, "sprite: %s\n", rt_last_error());
+        rt_check(1, "sprite(file)", __FILE__, __LINE__);
+        return;
+    }
+    rBuff = new buffer(r, width * height);
+    gBuff = new buffer(g, width * height);
+    bBuff = new buffer(b, width * height);
+    rt_free_planes(r, g, b);
+}
+
+int sprite::getBytes() { return (int)sizeof(float) * width * height * 3; }
+
+static_assert(sizeof(buffer) == sizeof(rt_buffer), "buffer must match rt_buffer");
+static_assert(sizeof(sprite) == sizeof(rt_sprite), "sprite must match rt_sprite");
+
+// ---- globals, kernel.cu:1692-1702 ----
+static int light_size = 3;
+static rt_light lights[RT_MAX_LIGHTS];
+static rt_camera cam = {{4, 3, 10}, {0, 0, 1}, 0.f, 180.f, -20.f};   // kernel.cu:1695, :261
+static rt_object *objs = nullptr;
+static rt_skybox *Skybox = nullptr;
+static float aspect = 0.f;
+
+static int cfg_sphere_count = 1024;      // the reference ships 0 (kernel.cu:1231); BASELINE configs set it
+static unsigned int cfg_seed = 1;        // un-seeded MSVC rand() starts from state 1
+
+// ---- persistent per-resolution frame resources ----
+static struct FrameRes {
+    uint32_t *d_pixels = nullptr;
+    uint32_t *h_pixels = nullptr;   // pinned
+    int width = 0, height = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_ms = 0.0;
+} fr;
+
+extern "C" int rt_config_set_sphere_count(int n)
+{
+    if (n < 0) return RT_ERR_INVALID;
+    cfg_sphere_count = n;
+    return RT_OK;
+}
+extern "C" int rt_config_set_seed(unsigned int seed)
+{
+    cfg_seed = seed;
+    return RT_OK;
+}
+extern "C" rt_camera *rt_config_camera(void) { return &cam; }
+extern "C" rt_light *rt_config_lights(int *count)
+{
+    if (count) *count = light_size;
+    return lights;
+}
+extern "C" double rt_last_frame_ms(void) { return fr.last_ms; }
+
+static const char *env_or(const char *name, const char *dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? v : dflt;
+}
+
+// onStart, kernel.cu:1704-1714 (+ object::loadMesh :1181-1207, skybox ctor :1120-1123)
+void onStart()
+{
+    aspect = rt_default_aspect();                                  // kernel.cu:1701
+
+    objs = (rt_object *)rt_managed_alloc(sizeof(rt_object));       // `new object()` through memManager
+    if (!objs) return;
+    memset(objs, 0, sizeof *objs);
+    objs->depth = 3;
+    objs->sphere_count = cfg_sphere_count;
+    // loadMesh: mesh/cube/plane stay empty (out of scope), spheres from the rand() replay
+    objs->s1 = (rt_sphere *)calloc((size_t)(cfg_sphere_count > 0 ? cfg_sphere_count : 1), sizeof(rt_sphere));
+    rt_generate_spheres(objs->s1, cfg_sphere_count, cfg_seed);
+    objs->texture = (rt_sprite *)new sprite(env_or("RT_OBJECT_TEXTURE", "synthetic:object"));
+    // sphereAllocMem, kernel.cu:1208-1212 (32 bytes per sphere, :1218-1220)
+    objs->d_spheres = (rt_sphere *)rt_managed_alloc(sizeof(float) * 8 * (size_t)(cfg_sphere_count > 0 ? cfg_sphere_count : 1));
+    if (objs->d_spheres && cfg_sphere_count > 0)
+        memcpy(objs->d_spheres, objs->s1, sizeof(float) * 8 * (size_t)cfg_sphere_count);
+
+    // skybox(img, 10000), kernel.cu:1120-1123, 1700
+    Skybox = (rt_skybox *)rt_managed_alloc(sizeof(rt_skybox));
+    if (!Skybox) return;
+    Skybox->skyboxTex = (rt_sprite *)new sprite(env_or("RT_SKY_TEXTURE", "synthetic:sky"));
+    Skybox->box = (rt_sphere *)rt_managed_alloc(sizeof(rt_sphere));
+    if (Skybox->box) rt_sphere_init(Skybox->box, 0, 0, 0, 10000);
+
+    // kernel.cu:1708-1712
+    const rt_light m_light = {{20, 20, 20}, 20, 1, 0, 0};
+    const rt_light b_light = {{0, 20, -20}, 20, 0, 0, 1};
+    const rt_light c_light = {{0, 20, 0}, 20, 0, 1, 0};
+    lights[0] = m_light;
+    lights[1] = b_light;
+    lights[2] = c_light;
+    light_size = 3;
+}
+
+static void release_frame_buffers()
+{
+    if (fr.d_pixels) checkHipErrors(hipFree(fr.d_pixels));
+    if (fr.h_pixels) checkHipErrors(hipHostFree(fr.h_pixels));
+    fr.d_pixels = fr.h_pixels = nullptr;
+    fr.width = fr.height = 0;
+}
+
+// update, kernel.cu:1762-1792
+void update()
+{
+    if (!objs || !Skybox) {
+        rt_check(1, "update() before onStart()", __FILE__, __LINE__);
+        return;
+    }
+    // checkKey() (kernel.cu:1716-1759) is keyboard input: out of scope; move the
+    // camera through rt_config_camera().
+
+    const int width = getScreenWidth(), height = getScreenHeight();   // kernel.cu:1771
+    if (width <= 0 || height <= 0) return;
+    cam.aspect = (float)height / width;                               // kernel.cu:1773
+
+    if (!fr.stream) {
+        checkHipErrors(hipStreamCreateWithFlags(&fr.stream, hipStreamNonBlocking));
+        checkHipErrors(hipEventCreate(&fr.ev0));
+        checkHipErrors(hipEventCreate(&fr.ev1));
+    }
+    if (width != fr.width || height != fr.height) {   // resize between frames keeps working
+        release_frame_buffers();
+        const size_t pixelSize = (size_t)width * (size_t)height * sizeof(unsigned int);
+        checkHipErrors(hipMalloc((void **)&fr.d_pixels, pixelSize));
+        checkHipErrors(hipHostMalloc((void **)&fr.h_pixels, pixelSize, hipHostMallocDefault));
+        fr.width = width;
+        fr.height = height;
+    }
+
+    checkHipErrors(hipEventRecord(fr.ev0, fr.stream));
+    const int rc = rt_launch_raytrace(fr.d_pixels, width, height, aspect, objs, lights, light_size, cam, Skybox,
+                                      fr.stream);
+    if (rc != RT_OK) {
+        fprintf(stderr, "update: %s\n", rt_last_error());
+        rt_check(rc, "rt_launch_raytrace", __FILE__, __LINE__);
+        return;
+    }
+    checkHipErrors(hipGetLastError());                                // kernel.cu:1785
+    checkHipErrors(hipEventRecord(fr.ev1, fr.stream));
+    checkHipErrors(hipMemcpyAsync(fr.h_pixels, fr.d_pixels, (size_t)width * height * sizeof(unsigned int),
+                                  hipMemcpyDeviceToHost, fr.stream));
+    checkHipErrors(hipStreamSynchronize(fr.stream));                  // kernel.cu:1786
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, fr.ev0, fr.ev1) == hipSuccess) fr.last_ms = ms;
+
+    setPixelBuff(fr.h_pixels);                                        // kernel.cu:1788
+}
+
+extern "C" void rt_on_start(void) { onStart(); }
+extern "C" void rt_update(void) { update(); }

@@ -1,0 +1,786 @@
+// rt_kernels.hip -- gfx950 (MI355X) kernels for the ray-tracing hot path.
+//
+// What is computed is the reference's `rayTrace` kernel restricted to its
+// sphere path (/root/reference/kernel.cu:1614-1690 and callees: castRay
+// :1287-1431, castLightRay :1432-1544, sphere::intersect :292-354,
+// skybox::getFColor :1146-1166, rgbToInt :546-556). How it is computed is not
+// the reference's one-thread-per-pixel brute force:
+//
+//   * one wave64 owns a TW x (64/TW) pixel tile; a 256-thread workgroup stages
+//     the sphere table {cx,cy,cz,radius^2} into LDS once;
+//   * per tile the wave cooperatively culls the table against a conservative
+//     bound of the tile's rays (a cone for the primary rays, a cone-capped beam
+//     for each light's shadow rays), ballot-compacts the survivors IN LIST
+//     ORDER into a per-wave LDS list, and only those are tested; every lane
+//     reads the same list entry (LDS broadcast);
+//   * every value that decides a pixel (the quadratic, sqrt, divisions, the
+//     shadow-sample construction) is evaluated with exactly the reference's
+//     IEEE binary32/binary64 operations -- this file is compiled with
+//     -ffp-contract=off and correctly rounded divide/sqrt; only the culling
+//     bounds use fast approximate math, and they are padded so that a culled
+//     sphere is one whose exact test would have returned false;
+//   * shadow rays leave their loop through a wave-wide "all lanes occluded".
+//
+// A sphere skipped by culling can never change the closest hit (it is not hit)
+// nor an any-hit result, and survivors keep their list order, so first-index-
+// wins ties (kernel.cu:1335) resolve identically: the output is bit-identical
+// to the brute-force loops (template CULL=false), which tests check.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_device.h"
+#include "rt_math.h"
+
+namespace {
+
+struct V3 {
+    float x, y, z;
+};
+
+// ---------------------------------------------------------------------------
+// wave64 helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float uniform(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ int lane_prefix(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+// Lanes of one wave exchange data through LDS without a workgroup barrier.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------
+// exact (reference-order) vector helpers, kernel.cu:46-108
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+
+// normalise(vec3d&): l = sqrtf(dot); if (l != 0) v /= l (in place) and return it,
+// else return (0,0,0) leaving v alone. The reference divides in binary64 and
+// narrows; for binary32 operands that equals the correctly rounded binary32
+// quotient (53 >= 2*24+2), so a float division reproduces it bit for bit.
+__device__ __forceinline__ V3 normalise_inplace(V3 &v)
+{
+    const float l = __builtin_sqrtf(dot3(v, v));
+    if (l != 0.f) {
+        v.x = v.x / l;
+        v.y = v.y / l;
+        v.z = v.z / l;
+        return v;
+    }
+    return V3{0.f, 0.f, 0.f};
+}
+
+// float -> int of the implicit conversions at kernel.cu:1653, 1157-1158, 1682:
+// truncation toward zero, NaN -> 0, saturating (v_cvt_i32_f32 semantics, which
+// are also CUDA's cvt.rzi.s32.f32).
+__device__ __forceinline__ int f2i(float v) { return (int)v; }
+
+// rgbToInt, kernel.cu:547-556
+__device__ __forceinline__ unsigned rgb_to_int(int r, int g, int b)
+{
+    if (r > 255) r = 255;
+    if (g > 255) g = 255;
+    if (b > 255) b = 255;
+    return (unsigned)(((r & 0xff) << 16) + ((g & 0xff) << 8) + (b & 0xff));
+}
+
+// ---------------------------------------------------------------------------
+// sphere::intersect, kernel.cu:293-354, on a table entry {cx,cy,cz,radius*radius}
+// ---------------------------------------------------------------------------
+struct RayK {          // a ray plus the per-ray constants of the quadratic
+    float ox, oy, oz;
+    float dx, dy, dz;
+    float a2;          // 2*A
+    float a4;          // 4*A
+    float h_sure;      // h < -h_sure  =>  t >= RT_T_MIN for sure (see shadow loop)
+};
+
+__device__ __forceinline__ RayK make_ray(V3 o, V3 d)
+{
+    RayK r;
+    r.ox = o.x; r.oy = o.y; r.oz = o.z;
+    r.dx = d.x; r.dy = d.y; r.dz = d.z;
+    const float A = (d.x * d.x + d.y * d.y) + d.z * d.z;
+    r.a2 = 2.f * A;
+    r.a4 = 4.f * A;
+    r.h_sure = 2.0e-4f * A;
+    return r;
+}
+
+struct Quad {  // B, B*B and the discriminant, in the reference's evaluation order
+    float h, B, BB, disc;
+};
+
+__device__ __forceinline__ Quad quadratic(const RayK &r, float4 s)
+{
+    const float ocx = r.ox - s.x, ocy = r.oy - s.y, ocz = r.oz - s.z;
+    Quad q;
+    q.h = (r.dx * ocx + r.dy * ocy) + r.dz * ocz;
+    q.B = 2.f * q.h;
+    const float C = ((ocx * ocx + ocy * ocy) + ocz * ocz) - s.w;
+    q.BB = q.B * q.B;
+    q.disc = q.BB - r.a4 * C;
+    return q;
+}
+
+// The tail of intersect once B and the discriminant are known.
+__device__ __forceinline__ bool intersect_tail(const RayK &r, const Quad &q, float &t)
+{
+    const float sq = __builtin_sqrtf(q.disc);
+    t = (-q.B + sq) / r.a2;
+    if (t == 0.f) return true;
+    if (t >= RT_T_MIN) {
+        const float t2 = (-q.B - sq) / r.a2;
+        if (t > t2) t = t2;
+        return true;
+    }
+    return false;
+}
+
+// A ray that starts outside a sphere whose centre lies behind it has B > 0 and
+// disc < B*B; then sqrt(disc) < B, t < 0 strictly and intersect() is false. The
+// factor keeps sqrt(disc) below B even after rounding, so the `t == 0` clause
+// (kernel.cu:338) cannot fire. Purely a shortcut: when in doubt the full tail runs.
+#define RT_BEHIND_FACTOR 0.99999f
+
+// ---------------------------------------------------------------------------
+// conservative culling
+// ---------------------------------------------------------------------------
+struct Beam {        // all members wave-uniform
+    float ax, ay, az;   // a point on the axis
+    float ux, uy, uz;   // unit axis
+    float smin;         // rays start at axial coordinate >= smin
+    float r0;           // ... within r0 of the axis
+    float k;            // and spread with slope k = tan(theta)
+};
+
+// Keep sphere s unless no ray inside the beam can make intersect() return true.
+// intersect() is true only if the float discriminant is >= 0, which (rounding
+// included) needs the ray's line within sqrt(R^2 + eps*(1+|oc|^2)) of the centre
+// (R^2 = s.w is the squared effective radius), and a far root >= 0.
+__device__ __forceinline__ bool beam_keeps(const Beam &b, float4 s)
+{
+    const float vx = s.x - b.ax, vy = s.y - b.ay, vz = s.z - b.az;
+    const float vv = __builtin_fmaf(vx, vx, __builtin_fmaf(vy, vy, vz * vz));
+    const float sa = __builtin_fmaf(vx, b.ux, __builtin_fmaf(vy, b.uy, vz * b.uz));
+    const float d2 = __builtin_fmaxf(__builtin_fmaf(-sa, sa, vv), 0.f);
+    // padded radius: rounding noise of the exact test + slack of this test
+    const float rc2 = s.w + __builtin_fmaf(4.0e-5f, vv, 1.0e-3f);
+    const float rc = __builtin_amdgcn_sqrtf(rc2) * 1.0001f;
+    const float reach = sa + rc - b.smin;
+    const float rad = __builtin_fmaf(b.k, __builtin_fmaxf(reach, 0.f), b.r0) + rc;
+    return (reach >= 0.f) && (d2 <= rad * rad * 1.0005f);
+}
+
+template <bool STATS>
+__device__ __forceinline__ int build_list(const float4 *tab, int n, float4 *list, const Beam &b,
+                                          int lane, unsigned long long &n_cull)
+{
+    int count = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const float4 s = tab[i < n ? i : n - 1];
+        const bool keep = (i < n) && beam_keeps(b, s);
+        const unsigned long long m = __ballot(keep);
+        const int pos = count + lane_prefix(m);
+        if (keep && pos < RT_LIST_CAP) list[pos] = s;
+        count += __popcll(m);
+        if (STATS) n_cull += 64;
+    }
+    wave_lds_sync();
+    return count;
+}
+
+
+// ---------------------------------------------------------------------------
+// castLightRay's sample construction, kernel.cu:1438-1468 (exact)
+// ---------------------------------------------------------------------------
+struct ShadowChain {
+    V3 toL;            // keeps being re-normalised in place by the reference
+    bool stable;
+    float angle;
+    float m00, m01, m02, m10, m11, m12, m20, m21, m22;
+
+    __device__ __forceinline__ void begin(V3 lpos, V3 start)
+    {
+        // toL = normalise(l.pos - start), kernel.cu:1438
+        toL = V3{lpos.x - start.x, lpos.y - start.y, lpos.z - start.z};
+        normalise_inplace(toL);
+        stable = false;
+        angle = 0.f;
+        m00 = m01 = m02 = m10 = m11 = m12 = m20 = m21 = m22 = 0.f;
+    }
+
+    // Direction of sample j. Everything up to the rotation matrix depends on j
+    // only through toL, which normalise() keeps re-normalising in place
+    // (kernel.cu:1465-1466). Once two more normalisations leave toL
+    // bit-identical, every later iteration reproduces the same values, so the
+    // block is skipped (70 % of lanes are stable after j = 0, 99.6 % after j = 1).
+    __device__ __forceinline__ V3 direction(const RtFrameConsts &fc, const RtLightDev &L, V3 start, int j)
+    {
+        const V3 lpos{L.px, L.py, L.pz};
+        if (!stable || fc.force_slow) {
+            const V3 tin = toL;
+            // P = cross(toL, (0,1,0)), kernel.cu:1444
+            const V3 P{toL.y * 0.f - toL.z * 1.f, toL.z * 0.f - toL.x * 0.f, toL.x * 1.f - toL.y * 0.f};
+            V3 e0{(lpos.x + P.x * L.size) - start.x, (lpos.y + P.y * L.size) - start.y,
+                  (lpos.z + P.z * L.size) - start.z};
+            const V3 toEdge = normalise_inplace(e0);                       // kernel.cu:1450
+            angle = rtm::cosf_rt(dot3(toL, toEdge) * 2.f);                 // kernel.cu:1451
+            // axis = normalise(cross((0,0,1), normalise(toL))), kernel.cu:1465
+            const V3 n1 = normalise_inplace(toL);
+            V3 ax0{0.f * n1.z - 1.f * n1.y, 1.f * n1.x - 0.f * n1.z, 0.f * n1.y - 0.f * n1.x};
+            const V3 axis = normalise_inplace(ax0);
+            // nAngle = acosf(dot(normalise(toL), (0,0,1))), kernel.cu:1466
+            const V3 n2 = normalise_inplace(toL);
+            const float nAngle = rtm::acosf_rt((n2.x * 0.f + n2.y * 0.f) + n2.z * 1.f);
+            float sn, cs;
+            rtm::sincosf_rt(nAngle, sn, cs);
+            const float omc = 1.f - cs;
+            // rotate(nAngle, axis), kernel.cu:1267-1277 (non-standard on purpose)
+            m00 = cs + axis.x * axis.x;
+            m01 = axis.x * axis.y * omc - axis.z * sn;
+            m02 = axis.x * axis.z * omc - axis.y * sn;
+            m10 = axis.y * axis.x * omc + axis.z * sn;
+            m11 = cs + axis.y * axis.y * omc;
+            m12 = axis.y * axis.z * omc - axis.x * sn;
+            m20 = axis.z * axis.x * omc - axis.y * sn;
+            m21 = axis.z * axis.y * omc + axis.x * sn;
+            m22 = cs + axis.z * axis.z * omc;
+            stable = (toL.x == tin.x) && (toL.y == tin.y) && (toL.z == tin.z);
+        }
+        const float z = fc.jf[j] * (1.0f - angle) + angle;                 // kernel.cu:1453
+        const float sq = __builtin_sqrtf(1.f - z * z);                     // kernel.cu:1462-1463
+        const float x = sq * fc.jcos[j];
+        const float y = sq * fc.jsin[j];
+        // multiply(rot, {x,y,z}), kernel.cu:123-125
+        const V3 rv{(x * m00 + y * m10) + z * m20, (x * m01 + y * m11) + z * m21,
+                    (x * m02 + y * m12) + z * m22};
+        V3 nd{lpos.x - rv.x, lpos.y - rv.y, lpos.z - rv.z};
+        return normalise_inplace(nd);                                      // kernel.cu:1468
+    }
+};
+
+// One shadow ray against one table entry: updates `shadowed` (any-hit,
+// kernel.cu:1504-1508). Two shortcuts decide most entries without sqrt/div:
+// h < -h_sure puts t above RT_T_MIN (-B >= 2*h_sure and sqrt(disc) >= 0), and
+// "behind" (see RT_BEHIND_FACTOR) makes t strictly negative.
+__device__ __forceinline__ void shadow_test(const RayK &sr, float4 s, bool &shadowed, bool force_slow)
+{
+    const Quad q = quadratic(sr, s);
+    bool need;
+    if (force_slow) {
+        need = !shadowed;
+    } else {
+        const bool cand = (q.disc >= 0.f) && !shadowed;
+        const bool sure = cand && (q.h < -sr.h_sure);
+        const bool behind = (q.h > 0.f) && (q.disc < q.BB * RT_BEHIND_FACTOR);
+        shadowed = shadowed || sure;
+        need = cand && !sure && !behind;
+    }
+    if (__any(need)) {
+        if (need) {
+            float t;
+            if (intersect_tail(sr, q, t)) shadowed = true;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// the frame kernel
+// ---------------------------------------------------------------------------
+template <int TW, bool CULL, bool STATS>
+__global__ __launch_bounds__(64 * RT_WAVES_PER_WG) void rt_trace_tiles(const RtFrameConsts fc,
+                                                                     const float4 *__restrict__ spheres)
+{
+    constexpr int TH = 64 / TW;
+    constexpr int WGX = (TW <= 16) ? 2 : 1;   // wave tiles per workgroup in x
+    extern __shared__ float4 lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int n = fc.n_spheres;
+    const int n_pad = (n + 63) & ~63;
+
+    // ---- stage the sphere table into LDS (coalesced 16 B/lane) ----
+    float4 *tab = lds;
+    for (int i = tid; i < n; i += 64 * RT_WAVES_PER_WG) tab[i] = spheres[i];
+    __syncthreads();
+    float4 *mylist = lds + n_pad + wave * RT_LIST_CAP;
+
+    const int tile_x = (blockIdx.x * WGX + (wave % WGX)) * TW;
+    const int tile_y = fc.y0 + (blockIdx.y * (RT_WAVES_PER_WG / WGX) + (wave / WGX)) * TH;
+    const int px = tile_x + (lane % TW);
+    const int py = tile_y + (lane / TW);
+    const bool valid = (px < fc.width) && (py < fc.y1);
+    if (!__any(valid)) return;   // wave-uniform; after the only workgroup barrier
+
+    unsigned long long st_primary = 0, st_shadow = 0, st_cull = 0, st_slots = 0, st_entries = 0,
+                       st_overflow = 0, st_hits = 0, st_unshadowed = 0;
+
+    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f;
+
+    for (int sample = 0; sample < fc.spp; ++sample) {
+        // ================= primary ray, kernel.cu:1624-1631 =================
+        const int sidx = fc.sample_base + sample;
+        const double tx_d = (2.0 * ((double)px + fc.off_x[sidx])) / fc.width_d;
+        const double ty_d = (2.0 * ((double)py + fc.off_y[sidx])) / fc.height_d;
+        const float dx = (float)(fc.aspect_d * tx_d - 1.0);
+        const float dy = (float)((fc.aspect_d * ty_d) * fc.hw_d - 1.0);
+        V3 dir{dx, dy, fc.eye_nz};   // (dx,dy,0) - (0,0,-1/aspect)
+        normalise_inplace(dir);
+        // camera::rotateDir, kernel.cu:252-257 (cos/sin hoisted to the host)
+        V3 D;
+        {
+            const float y = dir.y * fc.cos_pitch - dir.z * fc.sin_pitch;
+            float z = dir.y * fc.sin_pitch + dir.z * fc.cos_pitch;
+            const float x = dir.x * fc.cos_yaw + z * fc.sin_yaw;
+            z = -dir.x * fc.sin_yaw + z * fc.cos_yaw;
+            D = V3{x, y, z};
+        }
+        const V3 O{fc.org_x, fc.org_y, fc.org_z};
+        const RayK pr = make_ray(O, D);
+
+        // ================= castRay, sphere branch =================
+        const float4 *plist = tab;
+        int pcount = n;
+        if (CULL) {
+            // cone around the tile's mean direction, apex at the (shared) origin
+            float sx = wave_sum(D.x), sy = wave_sum(D.y), sz = wave_sum(D.z);
+            const float inv = __builtin_amdgcn_rsqf(__builtin_fmaf(sx, sx, __builtin_fmaf(sy, sy, sz * sz)));
+            Beam b;
+            b.ux = uniform(sx * inv); b.uy = uniform(sy * inv); b.uz = uniform(sz * inv);
+            const float cx = D.y * b.uz - D.z * b.uy, cy = D.z * b.ux - D.x * b.uz, cz = D.x * b.uy - D.y * b.ux;
+            float s2 = wave_max(__builtin_fmaf(cx, cx, __builtin_fmaf(cy, cy, cz * cz)));
+            s2 = uniform(s2);
+            // s2 is sin^2 of the largest deviation (|D| = 1 up to rounding)
+            const bool ok = (s2 < 0.25f);   // NaN or a degenerate tile: do not cull
+            const float sn = __builtin_amdgcn_sqrtf(s2) * 1.01f + 1.0e-5f;
+            b.k = sn * __builtin_amdgcn_rsqf(1.f - sn * sn);
+            b.ax = O.x; b.ay = O.y; b.az = O.z;
+            b.smin = 0.f;
+            b.r0 = 1.0e-4f;
+            if (ok) {
+                const int c = build_list<STATS>(tab, n, mylist, b, lane, st_cull);
+                if (c <= RT_LIST_CAP) {
+                    plist = mylist;
+                    pcount = c;
+                } else if (STATS) {
+                    st_overflow += 1;
+                }
+                if (STATS) st_entries += (unsigned long long)(c <= RT_LIST_CAP ? c : n);
+            }
+        }
+
+        float nt = __builtin_inff();
+        float hcx = 0.f, hcy = 0.f, hcz = 0.f;   // centre of the closest sphere
+        for (int e = 0; e < pcount; ++e) {
+            const float4 s = plist[e];
+            const Quad q = quadratic(pr, s);
+            bool need = (q.disc >= 0.f);
+            if (!fc.force_slow) need = need && !(q.h > 0.f && q.disc < q.BB * RT_BEHIND_FACTOR);
+            if (fc.force_slow) need = true;
+            if (__any(need)) {
+                if (need) {
+                    float t;
+                    if (intersect_tail(pr, q, t)) {
+                        if (t < nt) {   // strict: first index wins ties (kernel.cu:1335)
+                            nt = t;
+                            hcx = s.x; hcy = s.y; hcz = s.z;
+                        }
+                    }
+                }
+            }
+            if (STATS) { st_primary += __popcll(__ballot(valid)); st_slots += 64; }
+        }
+        if (CULL) wave_lds_sync();   // the list is rebuilt below
+
+        const bool hit = valid && (nt != __builtin_inff());   // kernel.cu:1374
+        float cr, cg, cb;   // this sample's colour
+
+        // ================= miss: skybox::getFColor, kernel.cu:1147-1166 =================
+        if (valid && !hit) {
+            const float4 sk = make_float4(fc.sky_cx, fc.sky_cy, fc.sky_cz, fc.sky_r2);
+            const Quad q = quadratic(pr, sk);
+            float t;
+            intersect_tail(pr, q, t);   // the boolean is ignored there, t is used as left
+            const V3 hp{O.x + D.x * t, O.y + D.y * t, O.z + D.z * t};
+            V3 nrm{hp.x - sk.x, hp.y - sk.y, hp.z - sk.z};
+            normalise_inplace(nrm);
+            const int ix = f2i((1.f + rtm::atan2f_rt(nrm.z, nrm.x) / 3.1415f) * 0.5f * (float)fc.sky_w);
+            const int iy = f2i(rtm::acosf_rt(nrm.y) / 3.1415f * (float)fc.sky_h);
+            int idx = iy * fc.sky_w + ix;
+            const int last = fc.sky_w * fc.sky_h - 1;
+            idx = idx < 0 ? 0 : (idx > last ? last : idx);   // documented clamp (reference is UB there)
+            cr = fc.sky_r[idx];
+            cg = fc.sky_g[idx];
+            cb = fc.sky_b[idx];
+        }
+
+        // ================= hit: shade, kernel.cu:1396-1405, 1643-1677 =================
+        V3 start{0.f, 0.f, 0.f}, normal{0.f, 1.f, 0.f};
+        float tr = 0.f, tg = 0.f, tb = 0.f;
+        if (hit) {
+            const V3 new_org{O.x + D.x * nt, O.y + D.y * nt, O.z + D.z * nt};
+            normal = V3{new_org.x - hcx, new_org.y - hcy, new_org.z - hcz};
+            normalise_inplace(normal);
+            // tx, ty: the literals 1, 3.1415, 0.5 make these binary64 expressions
+            const float tx = (float)((1.0 + (double)rtm::atan2f_rt(normal.z, normal.x) / 3.1415) * 0.5);
+            const float ty = (float)((double)rtm::acosf_rt(normal.y) / 3.1415);
+            int ci = f2i(ty * (float)fc.tex_h) * fc.tex_w + f2i(tx * (float)fc.tex_w);
+            const int last = fc.tex_w * fc.tex_h - 1;
+            ci = ci < 0 ? 0 : (ci > last ? last : ci);       // documented clamp
+            tr = fc.tex_r[ci];
+            tg = fc.tex_g[ci];
+            tb = fc.tex_b[ci];
+            // start_O = normal * 0.00001 + new_org, kernel.cu:1647
+            start = V3{normal.x * 0.00001f + new_org.x, normal.y * 0.00001f + new_org.y,
+                       normal.z * 0.00001f + new_org.z};
+            if (STATS) st_hits += 1;
+        }
+
+        float fr = 0.f, fg = 0.f, fb = 0.f;
+        if (__any(hit)) {
+            const unsigned long long hitmask = __ballot(hit);
+            const int first = __builtin_ctzll(hitmask);
+            for (int li = 0; li < fc.n_lights; ++li) {
+                const RtLightDev L = fc.lights[li];
+                const V3 lpos{L.px, L.py, L.pz};
+
+                // toL = normalise(l.pos - start), kernel.cu:1438 (exact; the beam below
+                // is derived from it with fast math and padded)
+                V3 toL{lpos.x - start.x, lpos.y - start.y, lpos.z - start.z};
+                normalise_inplace(toL);
+
+                // ---------- conservative beam for this light's 10 x 64 rays ----------
+                const float4 *slist = tab;
+                int scount = n;
+                if (CULL) {
+                    bool ok = true;
+                    Beam b;
+                    b.ux = L.ux; b.uy = L.uy; b.uz = L.uz;
+                    // approximate sample directions from toL (fast math; padded below)
+                    float smax2 = 0.f;
+                    {
+                        const float c = toL.z;
+                        const float sn = __builtin_amdgcn_sqrtf(__builtin_fmaxf(1.f - c * c, 0.f));
+                        const float q2 = toL.x * toL.x + toL.y * toL.y;
+                        const float rq = q2 > 0.f ? __builtin_amdgcn_rsqf(q2) : 0.f;
+                        const float ax = -toL.y * rq, ay = toL.x * rq;   // axis = (0,0,1) x toL, az = 0
+                        const float omc = 1.f - c;
+                        // rotate(nAngle, axis), kernel.cu:1267-1277, with az = 0
+                        const float m00 = c + ax * ax, m01 = ax * ay * omc, m02 = -ay * sn;
+                        const float m10 = m01, m11 = c + ay * ay * omc, m12 = -ax * sn;
+                        const float m20 = -ay * sn, m21 = ax * sn, m22 = c;
+                        // P = toL x (0,1,0) = (-toL.z, 0, toL.x)
+                        const float ex = lpos.x - toL.z * L.size - start.x;
+                        const float ey = lpos.y - start.y;
+                        const float ez = lpos.z + toL.x * L.size - start.z;
+                        const float re = __builtin_amdgcn_rsqf(ex * ex + ey * ey + ez * ez);
+                        const float dte = (toL.x * ex + toL.y * ey + toL.z * ez) * re;
+                        const float angle = __cosf(2.f * dte);
+#pragma unroll
+                        for (int j = 0; j < RT_SHADOW_SAMPLES; ++j) {
+                            const float z = fc.jf[j] * (1.f - angle) + angle;
+                            const float sq = __builtin_amdgcn_sqrtf(__builtin_fmaxf(1.f - z * z, 0.f));
+                            const float x = sq * fc.jcos[j], y = sq * fc.jsin[j];
+                            const float wx = lpos.x - (x * m00 + y * m10 + z * m20);
+                            const float wy = lpos.y - (x * m01 + y * m11 + z * m21);
+                            const float wz = lpos.z - (x * m02 + y * m12 + z * m22);
+                            const float kx = wy * b.uz - wz * b.uy, ky = wz * b.ux - wx * b.uz,
+                                        kz = wx * b.uy - wy * b.ux;
+                            const float s2 = (kx * kx + ky * ky + kz * kz) *
+                                             __builtin_amdgcn_rcpf(wx * wx + wy * wy + wz * wz);
+                            // not fmaxf: a NaN must poison the bound so that culling is skipped
+                            smax2 = (s2 > smax2 || s2 != s2) ? s2 : smax2;
+                        }
+                    }
+                    if (!hit) smax2 = 0.f;
+                    const bool lane_bad = hit && !(smax2 < 0.25f);
+                    ok = !__any(lane_bad);
+                    const float s2w = uniform(wave_max(smax2));
+                    const float snw = __builtin_amdgcn_sqrtf(s2w) * 1.02f + 2.0e-3f;
+                    b.k = snw * __builtin_amdgcn_rsqf(__builtin_fmaxf(1.f - snw * snw, 0.05f));
+                    // origins: axis through the first hit lane's start
+                    b.ax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, start.x), first));
+                    b.ay = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, start.y), first));
+                    b.az = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, start.z), first));
+                    const float ox = start.x - b.ax, oy = start.y - b.ay, oz = start.z - b.az;
+                    const float so = ox * b.ux + oy * b.uy + oz * b.uz;
+                    const float perp2 = __builtin_fmaxf(ox * ox + oy * oy + oz * oz - so * so, 0.f);
+                    const float r2 = uniform(wave_max(hit ? perp2 : 0.f));
+                    const float smin = uniform(wave_min(hit ? so : 3.0e38f));
+                    ok = ok && (r2 < 1.0e30f) && (smin > -1.0e30f);
+                    b.r0 = __builtin_amdgcn_sqrtf(r2) * 1.001f + 1.0e-3f;
+                    b.smin = smin - 1.0e-3f - 1.0e-4f * __builtin_fabsf(smin);
+                    if (ok) {
+                        const int c = build_list<STATS>(tab, n, mylist, b, lane, st_cull);
+                        if (c <= RT_LIST_CAP) {
+                            slist = mylist;
+                            scount = c;
+                        } else if (STATS) {
+                            st_overflow += 1;
+                        }
+                        if (STATS) st_entries += (unsigned long long)(c <= RT_LIST_CAP ? c : n);
+                    }
+                }
+
+                // ---------- the 10 samples, kernel.cu:1442-1540 (exact) ----------
+                ShadowChain chain;
+                chain.begin(lpos, start);
+                int unshadowed = 0;
+#pragma unroll 1
+                for (int j = 0; j < RT_SHADOW_SAMPLES; ++j) {
+                    const V3 new_dir = chain.direction(fc, L, start, j);
+                    const RayK sr = make_ray(start, new_dir);
+                    // any-hit over the list, kernel.cu:1501-1510
+                    bool shadowed = !hit;   // lanes without a hit are simply done
+                    for (int e = 0; e < scount; ++e) {
+                        shadow_test(sr, slist[e], shadowed, fc.force_slow != 0);
+                        if (STATS) { st_shadow += __popcll(__ballot(hit)); st_slots += 64; }
+                        if (__all(shadowed)) break;
+                    }
+                    if (!shadowed) unshadowed += 1;   // b += 0.1, kernel.cu:1537-1539
+                }
+                if (CULL) wave_lds_sync();
+
+                if (hit) {
+                    // b after `unshadowed` float+=double steps, then b *= max(normal.toL, 0)
+                    float bsum = fc.btab[unshadowed];
+                    const float a = dot3(normal, chain.toL);                    // kernel.cu:1541
+                    bsum = bsum * (a > 0.f ? a : 0.f);
+                    fr = fr + bsum * L.r * tr;                                  // kernel.cu:1673-1675
+                    fg = fg + bsum * L.g * tg;
+                    fb = fb + bsum * L.b * tb;
+                    if (STATS) st_unshadowed += (unsigned long long)unshadowed;
+                }
+            }
+        }
+        if (hit) { cr = fr; cg = fg; cb = fb; }
+        if (valid) {
+            acc_r = acc_r + cr;
+            acc_g = acc_g + cg;
+            acc_b = acc_b + cb;
+        }
+    }
+
+    // ================= write-back =================
+    if (valid) {
+        const size_t o = (size_t)(py - fc.y0) * (size_t)fc.width + (size_t)px;
+        float w = (float)fc.spp;
+        if (fc.rgba) {
+            float4 *dst = reinterpret_cast<float4 *>(fc.rgba) + o;
+            if (fc.accumulate) {
+                const float4 old = *dst;
+                acc_r = old.x + acc_r;
+                acc_g = old.y + acc_g;
+                acc_b = old.z + acc_b;
+                w = old.w + w;
+            }
+            *dst = make_float4(acc_r, acc_g, acc_b, w);
+        }
+        if (fc.packed && fc.resolve) {
+            // mean over the frame's samples (x/1.0f is exact, so 1 spp is the
+            // reference's rgbToInt(fr*254, fg*254, fb*254), kernel.cu:1682/1688)
+            const float mr = acc_r / fc.sample_total, mg = acc_g / fc.sample_total,
+                        mb = acc_b / fc.sample_total;
+            fc.packed[o] = rgb_to_int(f2i(mr * 254.f), f2i(mg * 254.f), f2i(mb * 254.f));
+        }
+    }
+
+    if (STATS && fc.stats) {
+        // per-lane counters were kept wave-uniform except hits/unshadowed
+        const unsigned long long h = (unsigned long long)wave_sum((float)st_hits);
+        const unsigned long long u = (unsigned long long)wave_sum((float)st_unshadowed);
+        if (lane == 0) {
+            atomicAdd(&fc.stats[0], st_primary);
+            atomicAdd(&fc.stats[1], st_shadow);
+            atomicAdd(&fc.stats[2], st_cull);
+            atomicAdd(&fc.stats[3], h);
+            atomicAdd(&fc.stats[4], u);
+            atomicAdd(&fc.stats[5], st_slots);
+            atomicAdd(&fc.stats[6], st_entries);
+            atomicAdd(&fc.stats[7], st_overflow);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// diagnostics: scalar building blocks evaluated on the device (tests only)
+// ---------------------------------------------------------------------------
+__global__ void rt_dbg_math(int op, const float *a, const float *b, float *out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r;
+    switch (op) {
+    case 0: r = rtm::cosf_rt(a[i]); break;
+    case 1: r = rtm::sinf_rt(a[i]); break;
+    case 2: r = rtm::acosf_rt(a[i]); break;
+    default: r = rtm::atan2f_rt(a[i], b[i]); break;
+    }
+    out[i] = r;
+}
+
+__global__ void rt_dbg_intersect(const float4 *tab, const float *rays, int n, int *hit, float *t)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3 o{rays[6 * i + 0], rays[6 * i + 1], rays[6 * i + 2]};
+    const V3 d{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]};
+    const RayK r = make_ray(o, d);
+    const Quad q = quadratic(r, tab[i]);
+    float tt;
+    hit[i] = intersect_tail(r, q, tt) ? 1 : 0;
+    t[i] = tt;
+}
+
+
+// castLightRay for n independent (start, normal) pairs against the whole table
+// (brute force, no culling): the 10 sample directions and the returned brightness.
+__global__ void rt_dbg_light(const RtFrameConsts fc, const float4 *tab, const float *starts,
+                             const float *normals, int light_index, int n, float *dirs, float *bright)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    const int k = live ? i : 0;
+    const V3 start{starts[3 * k + 0], starts[3 * k + 1], starts[3 * k + 2]};
+    const V3 normal{normals[3 * k + 0], normals[3 * k + 1], normals[3 * k + 2]};
+    const RtLightDev L = fc.lights[light_index];
+    ShadowChain chain;
+    chain.begin(V3{L.px, L.py, L.pz}, start);
+    int unshadowed = 0;
+    for (int j = 0; j < RT_SHADOW_SAMPLES; ++j) {
+        const V3 d = chain.direction(fc, L, start, j);
+        if (live) {
+            dirs[30 * i + 3 * j + 0] = d.x;
+            dirs[30 * i + 3 * j + 1] = d.y;
+            dirs[30 * i + 3 * j + 2] = d.z;
+        }
+        const RayK sr = make_ray(start, d);
+        bool shadowed = !live;
+        for (int e = 0; e < fc.n_spheres; ++e) {
+            shadow_test(sr, tab[e], shadowed, fc.force_slow != 0);
+            if (__all(shadowed)) break;
+        }
+        if (!shadowed) unshadowed += 1;
+    }
+    if (live) {
+        float b = fc.btab[unshadowed];
+        const float a = dot3(normal, chain.toL);
+        bright[i] = b * (a > 0.f ? a : 0.f);
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// host-side launchers (called from rt_engine.cpp)
+// ---------------------------------------------------------------------------
+// Raise the dynamic-LDS limit of every instantiation once (a single workgroup may
+// use the whole 160 KiB). Not a stream operation, so it must not run inside a
+// graph capture: rt_graph_capture() calls this first.
+extern "C" hipError_t rt_dev_prepare(void)
+{
+    static bool done = false;
+    if (done) return hipSuccess;
+    hipError_t e = hipSuccess;
+#define RT_ATTR(TW, C, S)                                                                          \
+    if (e == hipSuccess)                                                                           \
+        e = hipFuncSetAttribute((const void *)rt_trace_tiles<TW, C, S>,                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+#define RT_ATTR_TW(TW) RT_ATTR(TW, true, true); RT_ATTR(TW, false, true); RT_ATTR(TW, true, false); RT_ATTR(TW, false, false)
+    RT_ATTR_TW(8);
+    RT_ATTR_TW(16);
+    RT_ATTR_TW(32);
+    RT_ATTR_TW(64);
+#undef RT_ATTR_TW
+#undef RT_ATTR
+    if (e == hipSuccess) done = true;
+    return e;
+}
+
+extern "C" hipError_t rt_dev_launch_trace(const RtFrameConsts *fc, const float4 *spheres, int tile_w,
+                                          int cull, int stats, hipStream_t stream)
+{
+    const int n_pad = (fc->n_spheres + 63) & ~63;
+    const size_t lds_bytes = (size_t)(n_pad + RT_WAVES_PER_WG * RT_LIST_CAP) * sizeof(float4);
+    const int band_h = fc->y1 - fc->y0;
+    const int th = 64 / tile_w;
+    const int wgx = (tile_w <= 16) ? 2 : 1;
+    const int wgy = RT_WAVES_PER_WG / wgx;
+    dim3 grid((fc->width + tile_w * wgx - 1) / (tile_w * wgx), (band_h + th * wgy - 1) / (th * wgy));
+    dim3 block(64 * RT_WAVES_PER_WG);
+    {
+        const hipError_t pe = rt_dev_prepare();
+        if (pe != hipSuccess) return pe;
+    }
+
+#define RT_LAUNCH(TW, C, S)                                                                        \
+    hipLaunchKernelGGL((rt_trace_tiles<TW, C, S>), grid, block, lds_bytes, stream, *fc, spheres)
+#define RT_LAUNCH_TW(TW)                                                                           \
+    do {                                                                                           \
+        if (stats) { if (cull) RT_LAUNCH(TW, true, true); else RT_LAUNCH(TW, false, true); }       \
+        else { if (cull) RT_LAUNCH(TW, true, false); else RT_LAUNCH(TW, false, false); }           \
+    } while (0)
+
+    switch (tile_w) {
+    case 8: RT_LAUNCH_TW(8); break;
+    case 16: RT_LAUNCH_TW(16); break;
+    case 32: RT_LAUNCH_TW(32); break;
+    case 64: RT_LAUNCH_TW(64); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef RT_LAUNCH_TW
+#undef RT_LAUNCH
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rt_dev_launch_dbg_math(int op, const float *a, const float *b, float *out, int n,
+                                             hipStream_t stream)
+{
+    hipLaunchKernelGGL(rt_dbg_math, dim3((n + 255) / 256), dim3(256), 0, stream, op, a, b, out, n);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rt_dev_launch_dbg_intersect(const float4 *tab, const float *rays, int n, int *hit,
+                                                  float *t, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rt_dbg_intersect, dim3((n + 255) / 256), dim3(256), 0, stream, tab, rays, n, hit, t);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rt_dev_launch_dbg_light(const RtFrameConsts *fc, const float4 *tab, const float *starts,
+                                              const float *normals, int light_index, int n, float *dirs,
+                                              float *bright, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rt_dbg_light, dim3((n + 63) / 64), dim3(64), 0, stream, *fc, tab, starts, normals,
+                       light_index, n, dirs, bright);
+    return hipGetLastError();
+}
