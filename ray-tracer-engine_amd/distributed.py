@@ -1,0 +1,48 @@
+"""Row-band multi-GPU split of one frame: one process per GPU,
+rank r renders rows band_rows(H, r, N) of the SAME frame (global y in the ray
+generation, /root/reference/kernel.cu:1624-1625), then ONE gather of the packed
+bands to rank 0 reassembles the image. No other collective is needed: pixels are
+independent (one store per thread, kernel.cu:1682/1688).
+
+Backend: "nccl" (= RCCL over xGMI) on GPUs; the same code runs on "gloo" with
+CPU tensors, which is how the host logic is tested without GPUs."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import band_rows
+
+
+def max_band_rows(height: int, world: int) -> int:
+    return max(band_rows(height, r, world)[1] - band_rows(height, r, world)[0] for r in range(world))
+
+
+def alloc_band(height: int, width: int, world: int, device, dtype=torch.int32) -> torch.Tensor:
+    """Band buffer padded to the largest band so that every rank contributes the
+    same element count to the gather (bands differ by at most one row)."""
+    return torch.zeros((max_band_rows(height, world), width), dtype=dtype, device=device)
+
+
+def gather_bands(band: torch.Tensor, dst: int = 0, group=None, out=None):
+    """One gather of equal-sized (padded) bands to `dst`. Returns the list of
+    per-rank bands on `dst`, None elsewhere. `out` lets the caller reuse buffers."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if rank == dst:
+        if out is None:
+            out = [torch.empty_like(band) for _ in range(world)]
+        dist.gather(band, out, dst=dst, group=group)
+        return out
+    dist.gather(band, None, dst=dst, group=group)
+    return None
+
+
+def assemble_frame(gathered, height: int) -> torch.Tensor:
+    """Drop each band's padding rows and stack the bands in rank order."""
+    world = len(gathered)
+    parts = []
+    for r, g in enumerate(gathered):
+        y0, y1 = band_rows(height, r, world)
+        parts.append(g[: y1 - y0])
+    return torch.cat(parts, dim=0)

@@ -1,0 +1,61 @@
+"""World-size-2 (and 3) `gloo` test of the multi-GPU host logic on CPU: band
+partition, padded single gather, reassembly. The band *renderer* here is the CPU
+oracle standing in for the HIP kernel (test infrastructure: the product itself
+has no CPU renderer); the thing under test is ray-tracer-engine_amd/distributed.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, w, h, n, out_path):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_py
+    import rt_amd
+    from scenes import Inputs
+    rt = rt_amd.load()
+    from ray_tracer_engine_amd import distributed as rd
+    inp = Inputs(rt, n)
+    y0, y1 = rt.band_rows(h, rank, world)
+    _, packed, _ = inp.oracle_render(oracle_py, w, h, y0=y0, y1=y1, nthreads=2)
+    band = rd.alloc_band(h, w, world, "cpu")
+    band[: y1 - y0] = torch.from_numpy(packed.view(np.int32))
+    got = rd.gather_bands(band, dst=0)
+    if rank == 0:
+        frame = rd.assemble_frame(got, h).numpy().view(np.uint32)
+        np.save(out_path, frame)
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,h", [(2, 54), (3, 53)])
+def test_band_gather_reassembles_frame(world, h, tmp_path, rt, oracle):
+    from scenes import Inputs
+    w, n = 96, 64
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), w, h, n, out), nprocs=world, join=True)
+    frame = np.load(out)
+    _, want, _ = Inputs(rt, n).oracle_render(oracle, w, h)
+    assert frame.shape == (h, w)
+    assert np.array_equal(frame, want)
