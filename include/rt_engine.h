@@ -133,6 +133,8 @@ typedef struct rt_launch_opts {
     int tile;                /* 0 default; else tile width in {8,16,32,64} (64 px/wave) */
     uint64_t *stats;         /* optional device array of RT_STATS_COUNT counters      */
     int force_slow_path;     /* testing: disable every exactness-preserving shortcut  */
+    int profile;             /* diagnostics: with `stats`, fill the per-phase cycle
+                                counters (RT_STAT_PHASE0..) instead of work counters   */
 } rt_launch_opts;
 
 enum { RT_STAT_PRIMARY_TESTS = 0, /* sphere tests issued for primary rays (per lane) */
@@ -143,7 +145,11 @@ enum { RT_STAT_PRIMARY_TESTS = 0, /* sphere tests issued for primary rays (per l
        RT_STAT_WAVE_TEST_SLOTS = 5, /* 64 x wave-level test iterations (issue slots) */
        RT_STAT_LIST_ENTRIES = 6,  /* sum of survivor-list lengths                     */
        RT_STAT_LIST_OVERFLOWS = 7,
-       RT_STATS_COUNT = 8 };
+       RT_STAT_PHASE0 = 8,        /* 8 per-phase cycle sums (profile builds only):
+                                     ray setup, primary cull, primary tests, shading+sky,
+                                     beam bound, shadow cull, sample construction, shadow tests */
+       RT_STAT_CLUSTERS = 16,     /* sum over waves of distinct hit spheres per tile  */
+       RT_STATS_COUNT = 24 };
 
 /* Same argument order and meaning as the reference kernel; references become
  * pointers; `stream` is a hipStream_t (NULL = default stream). `pixels` is a

@@ -30,9 +30,12 @@ except Exception:  # torch is optional for pure-host helpers
 
 RT_MAX_LIGHTS = 8
 RT_MAX_SPP = 16
-RT_STATS_COUNT = 8
+RT_STATS_COUNT = 24
 STAT_NAMES = ("primary_tests", "shadow_tests", "cull_tests", "hit_pixels", "unshadowed",
-              "wave_test_slots", "list_entries", "list_overflows")
+              "wave_test_slots", "list_entries", "list_overflows",
+              "cyc_ray_setup", "cyc_primary_cull", "cyc_primary_tests", "cyc_shade_sky", "cyc_beam_bound",
+              "cyc_shadow_cull", "cyc_sample_dirs", "cyc_shadow_tests",
+              "clusters", "r17", "r18", "r19", "r20", "r21", "r22", "r23")
 
 
 class RtError(RuntimeError):
@@ -89,7 +92,7 @@ class LaunchOpts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("rgba", C.c_void_p), ("y0", C.c_int), ("y1", C.c_int),
                 ("spp", C.c_int), ("sample_base", C.c_int), ("sample_total", C.c_int),
                 ("accumulate", C.c_int), ("resolve", C.c_int), ("cull", C.c_int), ("tile", C.c_int),
-                ("stats", C.c_void_p), ("force_slow_path", C.c_int)]
+                ("stats", C.c_void_p), ("force_slow_path", C.c_int), ("profile", C.c_int)]
 
 
 class FrameDesc(C.Structure):
@@ -286,7 +289,7 @@ class Scene:
 
     def frame_desc(self, width, height, *, pixels=0, rgba=0, cam=None, aspect=None, y0=0, y1=0, spp=1,
                    sample_base=0, sample_total=0, accumulate=False, resolve=0, cull=True, tile=0,
-                   stats=0, force_slow=False) -> FrameDesc:
+                   stats=0, force_slow=False, profile=False) -> FrameDesc:
         fd = FrameDesc()
         fd.struct_size = C.sizeof(FrameDesc)
         fd.width, fd.height = width, height
@@ -304,6 +307,7 @@ class Scene:
         o.tile = tile
         o.stats = stats
         o.force_slow_path = 1 if force_slow else 0
+        o.profile = 1 if profile else 0
         return fd
 
     def render_raw(self, fd: FrameDesc, stream=0):

@@ -38,7 +38,7 @@ struct RtFrameConsts {
     float sample_total;         // divisor at resolve time, as float
     int accumulate, resolve;
     int force_slow;
-    int pad0_;
+    int ablate;                 // diagnostics only (RT_ABLATE env): skip parts of the kernel to price them
 
     // primary-ray uniforms (kernel.cu:1624-1631, 248-258)
     double aspect_d;            // (double)aspect

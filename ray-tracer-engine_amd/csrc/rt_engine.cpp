@@ -321,6 +321,10 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
     fc->accumulate = o.accumulate ? 1 : 0;
     fc->resolve = (fd->pixels && o.resolve >= 0) ? 1 : 0;
     fc->force_slow = o.force_slow_path ? 1 : 0;
+    {   // timing experiments only: output is wrong when set
+        const char *ab = getenv("RT_ABLATE");
+        fc->ablate = ab ? atoi(ab) : 0;
+    }
 
     // kernel.cu:1624-1625
     const float aspect = fd->aspect;
@@ -344,10 +348,19 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
     for (int k = 0; k < total; ++k) rt_sample_offset(k, total, &fc->off_x[k], &fc->off_y[k]);
 
     // castLightRay sample constants, kernel.cu:1453-1454, 1462-1463, 1538
-    float b = 0;
-    for (int j = 0; j <= RT_SHADOW_SAMPLES; ++j) {
-        fc->btab[j] = b;
-        b = (float)(b + 0.1);
+    {   // the device uses literals for this sequence (brightness_steps); re-derive and compare
+        static const float kSteps[RT_SHADOW_SAMPLES + 1] = {
+            0x0.0p+0f, 0x1.99999ap-4f, 0x1.99999ap-3f, 0x1.333334p-2f, 0x1.99999ap-2f, 0x1.000000p-1f,
+            0x1.333334p-1f, 0x1.666668p-1f, 0x1.99999cp-1f, 0x1.ccccd0p-1f, 0x1.000002p+0f};
+        float b = 0;
+        for (int j = 0; j <= RT_SHADOW_SAMPLES; ++j) {
+            fc->btab[j] = b;
+            if (b != kSteps[j]) {
+                rt_set_error("internal: brightness step table mismatch at %d", j);
+                return RT_ERR_INVALID;
+            }
+            b = (float)(b + 0.1);
+        }
     }
     for (int j = 0; j < RT_SHADOW_SAMPLES; ++j) {
         const float jf = (float)j / 10;
@@ -401,7 +414,7 @@ extern "C" int rt_scene_render(rt_scene *s, const rt_frame_desc *fd, void *strea
     rc = tile_from_opts(fd->opts, &tile);
     if (rc != RT_OK) return rc;
     const int cull = (fd->opts.cull == 0) ? 0 : 1;
-    const int stats = fd->opts.stats ? 1 : 0;
+    const int stats = fd->opts.stats ? (fd->opts.profile ? 2 : 1) : 0;
     RT_HIP(rt_dev_launch_trace(&fc, s->d_spheres, tile, cull, stats, (hipStream_t)stream));
     return RT_OK;
 }

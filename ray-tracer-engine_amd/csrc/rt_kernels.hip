@@ -100,6 +100,27 @@ __device__ __forceinline__ V3 normalise_inplace(V3 &v)
 // are also CUDA's cvt.rzi.s32.f32).
 __device__ __forceinline__ int f2i(float v) { return (int)v; }
 
+// b after n executions of `b += 0.1` (float += double literal, kernel.cu:1538),
+// starting from 0: depends only on how many samples were unshadowed. Literals
+// instead of a table so that a per-lane n needs no memory (a kernarg array
+// indexed per lane would live in scratch); the host re-derives the sequence and
+// refuses to launch if it ever disagreed (rt_build_frame_consts).
+__device__ __forceinline__ float brightness_steps(int n)
+{
+    float b = 0x0.0p+0f;
+    b = n >= 1 ? 0x1.99999ap-4f : b;
+    b = n >= 2 ? 0x1.99999ap-3f : b;
+    b = n >= 3 ? 0x1.333334p-2f : b;
+    b = n >= 4 ? 0x1.99999ap-2f : b;
+    b = n >= 5 ? 0x1.000000p-1f : b;
+    b = n >= 6 ? 0x1.333334p-1f : b;
+    b = n >= 7 ? 0x1.666668p-1f : b;
+    b = n >= 8 ? 0x1.99999cp-1f : b;
+    b = n >= 9 ? 0x1.ccccd0p-1f : b;
+    b = n >= 10 ? 0x1.000002p+0f : b;
+    return b;
+}
+
 // rgbToInt, kernel.cu:547-556
 __device__ __forceinline__ unsigned rgb_to_int(int r, int g, int b)
 {
@@ -197,7 +218,7 @@ __device__ __forceinline__ bool beam_keeps(const Beam &b, float4 s)
     return (reach >= 0.f) && (d2 <= rad * rad * 1.0005f);
 }
 
-template <bool STATS>
+template <int STATS>
 __device__ __forceinline__ int build_list(const float4 *tab, int n, float4 *list, const Beam &b,
                                           int lane, unsigned long long &n_cull)
 {
@@ -210,7 +231,7 @@ __device__ __forceinline__ int build_list(const float4 *tab, int n, float4 *list
         const int pos = count + lane_prefix(m);
         if (keep && pos < RT_LIST_CAP) list[pos] = s;
         count += __popcll(m);
-        if (STATS) n_cull += 64;
+        if (STATS == 1) n_cull += 64;
     }
     wave_lds_sync();
     return count;
@@ -314,7 +335,9 @@ __device__ __forceinline__ void shadow_test(const RayK &sr, float4 s, bool &shad
 // ---------------------------------------------------------------------------
 // the frame kernel
 // ---------------------------------------------------------------------------
-template <int TW, bool CULL, bool STATS>
+// STATS: 0 = product kernel, 1 = work counters, 2 = per-phase cycle stamps
+// (s_memtime; a diagnostic build whose run time is never quoted).
+template <int TW, bool CULL, int STATS>
 __global__ __launch_bounds__(64 * RT_WAVES_PER_WG) void rt_trace_tiles(const RtFrameConsts fc,
                                                                      const float4 *__restrict__ spheres)
 {
@@ -342,7 +365,22 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG) void rt_trace_tiles(const RtF
     if (!__any(valid)) return;   // wave-uniform; after the only workgroup barrier
 
     unsigned long long st_primary = 0, st_shadow = 0, st_cull = 0, st_slots = 0, st_entries = 0,
-                       st_overflow = 0, st_hits = 0, st_unshadowed = 0;
+                       st_overflow = 0, st_hits = 0, st_unshadowed = 0, st_clusters = 0;
+
+    unsigned long long hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = 0;
+    auto phase = [&](int k) {   // charge the cycles since the previous stamp to phase k
+        if (STATS == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): s_memtime returns through it
+            __builtin_amdgcn_sched_barrier(0);
+            if (k >= 0) ph[k] += now - t_prev;
+            t_prev = now;
+        }
+    };
+    phase(-1);
 
     float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f;
 
@@ -367,6 +405,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG) void rt_trace_tiles(const RtF
         const V3 O{fc.org_x, fc.org_y, fc.org_z};
         const RayK pr = make_ray(O, D);
 
+        phase(0);
         // ================= castRay, sphere branch =================
         const float4 *plist = tab;
         int pcount = n;
@@ -391,17 +430,20 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG) void rt_trace_tiles(const RtF
                 if (c <= RT_LIST_CAP) {
                     plist = mylist;
                     pcount = c;
-                } else if (STATS) {
+                } else if (STATS == 1) {
                     st_overflow += 1;
                 }
-                if (STATS) st_entries += (unsigned long long)(c <= RT_LIST_CAP ? c : n);
+                if (STATS == 1) st_entries += (unsigned long long)(c <= RT_LIST_CAP ? c : n);
             }
         }
 
+        phase(1);
         float nt = __builtin_inff();
         float hcx = 0.f, hcy = 0.f, hcz = 0.f;   // centre of the closest sphere
+        float4 pcur = pcount > 0 ? plist[0] : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int e = 0; e < pcount; ++e) {
-            const float4 s = plist[e];
+            const float4 s = pcur;
+            pcur = plist[e + 1 < pcount ? e + 1 : e];   // keep one entry in flight
             const Quad q = quadratic(pr, s);
             bool need = (q.disc >= 0.f);
             if (!fc.force_slow) need = need && !(q.h > 0.f && q.disc < q.BB * RT_BEHIND_FACTOR);
@@ -417,9 +459,10 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG) void rt_trace_tiles(const RtF
                     }
                 }
             }
-            if (STATS) { st_primary += __popcll(__ballot(valid)); st_slots += 64; }
+            if (STATS == 1) { st_primary += __popcll(__ballot(valid)); st_slots += 64; }
         }
         if (CULL) wave_lds_sync();   // the list is rebuilt below
+        phase(2);
 
         const bool hit = valid && (nt != __builtin_inff());   // kernel.cu:1374
         float cr, cg, cb;   // this sample's colour
@@ -451,8 +494,13 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG) void rt_trace_tiles(const RtF
             normal = V3{new_org.x - hcx, new_org.y - hcy, new_org.z - hcz};
             normalise_inplace(normal);
             // tx, ty: the literals 1, 3.1415, 0.5 make these binary64 expressions
-            const float tx = (float)((1.0 + (double)rtm::atan2f_rt(normal.z, normal.x) / 3.1415) * 0.5);
-            const float ty = (float)((double)rtm::acosf_rt(normal.y) / 3.1415);
+            float tx, ty;
+            if (fc.ablate & 8) {
+                tx = normal.x; ty = normal.y;
+            } else {
+                tx = (float)((1.0 + (double)rtm::atan2f_rt(normal.z, normal.x) / 3.1415) * 0.5);
+                ty = (float)((double)rtm::acosf_rt(normal.y) / 3.1415);
+            }
             int ci = f2i(ty * (float)fc.tex_h) * fc.tex_w + f2i(tx * (float)fc.tex_w);
             const int last = fc.tex_w * fc.tex_h - 1;
             ci = ci < 0 ? 0 : (ci > last ? last : ci);       // documented clamp
@@ -462,13 +510,27 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG) void rt_trace_tiles(const RtF
             // start_O = normal * 0.00001 + new_org, kernel.cu:1647
             start = V3{normal.x * 0.00001f + new_org.x, normal.y * 0.00001f + new_org.y,
                        normal.z * 0.00001f + new_org.z};
-            if (STATS) st_hits += 1;
+            if (STATS == 1) st_hits += 1;
         }
 
+        phase(3);
         float fr = 0.f, fg = 0.f, fb = 0.f;
-        if (__any(hit)) {
-            const unsigned long long hitmask = __ballot(hit);
-            const int first = __builtin_ctzll(hitmask);
+        if (__any(hit) && !(fc.ablate & 16)) {
+            // A tile that straddles a silhouette sees several spheres at different
+            // depths; one beam around all of their shadow rays would be fat and its
+            // survivor list long. So the hit lanes are processed in groups that share
+            // the closest sphere (3.5 % of the 8x8 tiles at 4K see more than one):
+            // each group's origins lie on one small patch, its beam is thin, its
+            // list short -- and no wave runs orders of magnitude longer than the rest.
+            unsigned long long rem = __ballot(hit);
+            while (rem) {
+            const int first = __builtin_ctzll(rem);
+            const float gx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hcx), first));
+            const float gy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hcy), first));
+            const float gz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hcz), first));
+            const bool inc = hit && ((rem >> lane) & 1ull) && (lane == first || (hcx == gx && hcy == gy && hcz == gz));
+            rem &= ~__ballot(inc);
+            if (STATS == 1) st_clusters += 1;
             for (int li = 0; li < fc.n_lights; ++li) {
                 const RtLightDev L = fc.lights[li];
                 const V3 lpos{L.px, L.py, L.pz};
@@ -487,7 +549,8 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG) void rt_trace_tiles(const RtF
                     b.ux = L.ux; b.uy = L.uy; b.uz = L.uz;
                     // approximate sample directions from toL (fast math; padded below)
                     float smax2 = 0.f;
-                    {
+                    if (fc.ablate & 32) smax2 = 0.01f;
+                    else {
                         const float c = toL.z;
                         const float sn = __builtin_amdgcn_sqrtf(__builtin_fmaxf(1.f - c * c, 0.f));
                         const float q2 = toL.x * toL.x + toL.y * toL.y;
@@ -521,8 +584,8 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG) void rt_trace_tiles(const RtF
                             smax2 = (s2 > smax2 || s2 != s2) ? s2 : smax2;
                         }
                     }
-                    if (!hit) smax2 = 0.f;
-                    const bool lane_bad = hit && !(smax2 < 0.25f);
+                    if (!inc) smax2 = 0.f;
+                    const bool lane_bad = inc && !(smax2 < 0.25f);
                     ok = !__any(lane_bad);
                     const float s2w = uniform(wave_max(smax2));
                     const float snw = __builtin_amdgcn_sqrtf(s2w) * 1.02f + 2.0e-3f;
@@ -534,53 +597,69 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG) void rt_trace_tiles(const RtF
                     const float ox = start.x - b.ax, oy = start.y - b.ay, oz = start.z - b.az;
                     const float so = ox * b.ux + oy * b.uy + oz * b.uz;
                     const float perp2 = __builtin_fmaxf(ox * ox + oy * oy + oz * oz - so * so, 0.f);
-                    const float r2 = uniform(wave_max(hit ? perp2 : 0.f));
-                    const float smin = uniform(wave_min(hit ? so : 3.0e38f));
+                    const float r2 = uniform(wave_max(inc ? perp2 : 0.f));
+                    const float smin = uniform(wave_min(inc ? so : 3.0e38f));
                     ok = ok && (r2 < 1.0e30f) && (smin > -1.0e30f);
                     b.r0 = __builtin_amdgcn_sqrtf(r2) * 1.001f + 1.0e-3f;
                     b.smin = smin - 1.0e-3f - 1.0e-4f * __builtin_fabsf(smin);
+                    phase(4);
+                    if (fc.ablate & 4) { ok = false; scount = 0; }
                     if (ok) {
                         const int c = build_list<STATS>(tab, n, mylist, b, lane, st_cull);
                         if (c <= RT_LIST_CAP) {
                             slist = mylist;
                             scount = c;
-                        } else if (STATS) {
+                        } else if (STATS == 1) {
                             st_overflow += 1;
                         }
-                        if (STATS) st_entries += (unsigned long long)(c <= RT_LIST_CAP ? c : n);
+                        if (STATS == 1) st_entries += (unsigned long long)(c <= RT_LIST_CAP ? c : n);
+                        if (STATS == 1) {
+                            const int bin = c <= 8 ? 0 : c <= 16 ? 1 : c <= 32 ? 2 : c <= 64 ? 3 : c <= 128 ? 4 : c <= RT_LIST_CAP ? 5 : 6;
+                            hist[bin] += 1;
+                        }
                     }
                 }
 
+                phase(5);
                 // ---------- the 10 samples, kernel.cu:1442-1540 (exact) ----------
                 ShadowChain chain;
                 chain.begin(lpos, start);
                 int unshadowed = 0;
 #pragma unroll 1
                 for (int j = 0; j < RT_SHADOW_SAMPLES; ++j) {
-                    const V3 new_dir = chain.direction(fc, L, start, j);
+                    const V3 new_dir = (fc.ablate & 2) ? chain.toL : chain.direction(fc, L, start, j);
                     const RayK sr = make_ray(start, new_dir);
+                    phase(6);
                     // any-hit over the list, kernel.cu:1501-1510
-                    bool shadowed = !hit;   // lanes without a hit are simply done
-                    for (int e = 0; e < scount; ++e) {
-                        shadow_test(sr, slist[e], shadowed, fc.force_slow != 0);
-                        if (STATS) { st_shadow += __popcll(__ballot(hit)); st_slots += 64; }
-                        if (__all(shadowed)) break;
+                    bool shadowed = !inc;   // lanes outside the group are simply done
+                    const int scount_j = (fc.ablate & 1) ? 0 : scount;
+                    if (scount_j > 0) {
+                        float4 cur = slist[0];
+                        for (int e = 0; e < scount_j; ++e) {
+                            const float4 nxt = slist[e + 1 < scount_j ? e + 1 : e];   // keep one entry in flight
+                            shadow_test(sr, cur, shadowed, fc.force_slow != 0);
+                            cur = nxt;
+                            if (STATS == 1) { st_shadow += __popcll(__ballot(inc)); st_slots += 64; }
+                            if (__all(shadowed)) break;
+                        }
                     }
                     if (!shadowed) unshadowed += 1;   // b += 0.1, kernel.cu:1537-1539
+                    phase(7);
                 }
                 if (CULL) wave_lds_sync();
 
-                if (hit) {
+                if (inc) {
                     // b after `unshadowed` float+=double steps, then b *= max(normal.toL, 0)
-                    float bsum = fc.btab[unshadowed];
+                    float bsum = brightness_steps(unshadowed);
                     const float a = dot3(normal, chain.toL);                    // kernel.cu:1541
                     bsum = bsum * (a > 0.f ? a : 0.f);
                     fr = fr + bsum * L.r * tr;                                  // kernel.cu:1673-1675
                     fg = fg + bsum * L.g * tg;
                     fb = fb + bsum * L.b * tb;
-                    if (STATS) st_unshadowed += (unsigned long long)unshadowed;
+                    if (STATS == 1) st_unshadowed += (unsigned long long)unshadowed;
                 }
             }
+            }   // groups
         }
         if (hit) { cr = fr; cg = fg; cb = fb; }
         if (valid) {
@@ -614,7 +693,12 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG) void rt_trace_tiles(const RtF
         }
     }
 
-    if (STATS && fc.stats) {
+    phase(3);
+    if (STATS == 2 && fc.stats) {
+        if (lane == 0)
+            for (int k = 0; k < 8; ++k) atomicAdd(&fc.stats[8 + k], ph[k]);
+    }
+    if (STATS == 1 && fc.stats) {
         // per-lane counters were kept wave-uniform except hits/unshadowed
         const unsigned long long h = (unsigned long long)wave_sum((float)st_hits);
         const unsigned long long u = (unsigned long long)wave_sum((float)st_unshadowed);
@@ -627,6 +711,8 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG) void rt_trace_tiles(const RtF
             atomicAdd(&fc.stats[5], st_slots);
             atomicAdd(&fc.stats[6], st_entries);
             atomicAdd(&fc.stats[7], st_overflow);
+            for (int k = 0; k < 8; ++k) atomicAdd(&fc.stats[8 + k], hist[k]);
+            atomicAdd(&fc.stats[16], st_clusters);
         }
     }
 }
@@ -692,7 +778,7 @@ __global__ void rt_dbg_light(const RtFrameConsts fc, const float4 *tab, const fl
         if (!shadowed) unshadowed += 1;
     }
     if (live) {
-        float b = fc.btab[unshadowed];
+        float b = brightness_steps(unshadowed);
         const float a = dot3(normal, chain.toL);
         bright[i] = b * (a > 0.f ? a : 0.f);
     }
@@ -715,7 +801,7 @@ extern "C" hipError_t rt_dev_prepare(void)
     if (e == hipSuccess)                                                                           \
         e = hipFuncSetAttribute((const void *)rt_trace_tiles<TW, C, S>,                           \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-#define RT_ATTR_TW(TW) RT_ATTR(TW, true, true); RT_ATTR(TW, false, true); RT_ATTR(TW, true, false); RT_ATTR(TW, false, false)
+#define RT_ATTR_TW(TW) RT_ATTR(TW, true, 0); RT_ATTR(TW, false, 0); RT_ATTR(TW, true, 1); RT_ATTR(TW, false, 1); RT_ATTR(TW, true, 2); RT_ATTR(TW, false, 2)
     RT_ATTR_TW(8);
     RT_ATTR_TW(16);
     RT_ATTR_TW(32);
@@ -746,8 +832,9 @@ extern "C" hipError_t rt_dev_launch_trace(const RtFrameConsts *fc, const float4 
     hipLaunchKernelGGL((rt_trace_tiles<TW, C, S>), grid, block, lds_bytes, stream, *fc, spheres)
 #define RT_LAUNCH_TW(TW)                                                                           \
     do {                                                                                           \
-        if (stats) { if (cull) RT_LAUNCH(TW, true, true); else RT_LAUNCH(TW, false, true); }       \
-        else { if (cull) RT_LAUNCH(TW, true, false); else RT_LAUNCH(TW, false, false); }           \
+        if (stats == 2) { if (cull) RT_LAUNCH(TW, true, 2); else RT_LAUNCH(TW, false, 2); }        \
+        else if (stats == 1) { if (cull) RT_LAUNCH(TW, true, 1); else RT_LAUNCH(TW, false, 1); }   \
+        else { if (cull) RT_LAUNCH(TW, true, 0); else RT_LAUNCH(TW, false, 0); }                   \
     } while (0)
 
     switch (tile_w) {
