@@ -19,7 +19,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librt_engine.so")
+LIB_PATH = os.environ.get("RT_ENGINE_LIB") or os.path.join(_HERE, "csrc", "librt_engine.so")   # env: tuning builds only
 
 # torch bundles a HIP runtime with the same soname as /opt/rocm's; it has to be
 # in the process first so that the engine binds to that single runtime.

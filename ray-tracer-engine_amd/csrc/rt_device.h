@@ -11,7 +11,14 @@
 #define RT_DEV_MAX_LIGHTS 8
 #define RT_DEV_MAX_SPP 16
 #define RT_SHADOW_SAMPLES 10   // kernel.cu:1442 `for (int j = 0; j < 10; j++)`
-#define RT_LIST_CAP 256        // survivor-list capacity per wave (float4 entries in LDS)
+#ifndef RT_LIST_CAP
+#define RT_LIST_CAP 128        // survivor-list capacity per wave (float4 entries in LDS);
+                               // lists beyond it fall back to the whole table (never seen at C2-C5)
+#endif
+#ifndef RT_MIN_WAVES_PER_SIMD
+#define RT_MIN_WAVES_PER_SIMD 6 // __launch_bounds__ second argument: register budget 512/this
+                               // (measured at C3: 4 -> 3.03 ms, 6 -> 2.74 ms, 8 -> 2.82 ms)
+#endif
 #define RT_WAVES_PER_WG 4
 
 // Smallest binary32 >= 0.0001 (binary64): `t >= 0.0001` (kernel.cu:342) compares

@@ -338,7 +338,7 @@ __device__ __forceinline__ void shadow_test(const RayK &sr, float4 s, bool &shad
 // STATS: 0 = product kernel, 1 = work counters, 2 = per-phase cycle stamps
 // (s_memtime; a diagnostic build whose run time is never quoted).
 template <int TW, bool CULL, int STATS>
-__global__ __launch_bounds__(64 * RT_WAVES_PER_WG) void rt_trace_tiles(const RtFrameConsts fc,
+__global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void rt_trace_tiles(const RtFrameConsts fc,
                                                                      const float4 *__restrict__ spheres)
 {
     constexpr int TH = 64 / TW;
