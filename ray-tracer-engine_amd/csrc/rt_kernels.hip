@@ -540,6 +540,23 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                 V3 toL{lpos.x - start.x, lpos.y - start.y, lpos.z - start.z};
                 normalise_inplace(toL);
 
+                // A surface that faces away from the light gets b *= 0 at kernel.cu:1542
+                // whatever its ten shadow samples say, and fr + (0*l.r)*r leaves fr
+                // untouched. The reference's `a` uses toL after its in-place
+                // re-normalisations, which move it by an ulp or two, so only a clearly
+                // negative normal.toL (and finite factors, so that 0*x is 0) counts.
+                // Such lanes take no part in this light; if the whole group faces away
+                // the light is skipped. (Not applied in the brute-force build, which
+                // runs the reference's loops as written and is what tests compare with.)
+                bool lit = inc;
+                if (CULL && !fc.force_slow) {
+                    const float a0 = dot3(normal, toL);
+                    const float fin = (L.r * tr) * (L.g * tg) * (L.b * tb);   // finite iff all six are
+                    const bool away = (a0 < -1.0e-4f) && (__builtin_fabsf(fin) < __builtin_inff());
+                    lit = inc && !away;
+                    if (!__any(lit)) continue;
+                }
+
                 // ---------- conservative beam for this light's 10 x 64 rays ----------
                 const float4 *slist = tab;
                 int scount = n;
@@ -584,21 +601,22 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                             smax2 = (s2 > smax2 || s2 != s2) ? s2 : smax2;
                         }
                     }
-                    if (!inc) smax2 = 0.f;
-                    const bool lane_bad = inc && !(smax2 < 0.25f);
+                    if (!lit) smax2 = 0.f;
+                    const bool lane_bad = lit && !(smax2 < 0.25f);
                     ok = !__any(lane_bad);
                     const float s2w = uniform(wave_max(smax2));
                     const float snw = __builtin_amdgcn_sqrtf(s2w) * 1.02f + 2.0e-3f;
                     b.k = snw * __builtin_amdgcn_rsqf(__builtin_fmaxf(1.f - snw * snw, 0.05f));
-                    // origins: axis through the first hit lane's start
-                    b.ax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, start.x), first));
-                    b.ay = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, start.y), first));
-                    b.az = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, start.z), first));
+                    // origins: axis through the first participating lane's start
+                    const int lead = __builtin_ctzll(__ballot(lit));
+                    b.ax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, start.x), lead));
+                    b.ay = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, start.y), lead));
+                    b.az = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, start.z), lead));
                     const float ox = start.x - b.ax, oy = start.y - b.ay, oz = start.z - b.az;
                     const float so = ox * b.ux + oy * b.uy + oz * b.uz;
                     const float perp2 = __builtin_fmaxf(ox * ox + oy * oy + oz * oz - so * so, 0.f);
-                    const float r2 = uniform(wave_max(inc ? perp2 : 0.f));
-                    const float smin = uniform(wave_min(inc ? so : 3.0e38f));
+                    const float r2 = uniform(wave_max(lit ? perp2 : 0.f));
+                    const float smin = uniform(wave_min(lit ? so : 3.0e38f));
                     ok = ok && (r2 < 1.0e30f) && (smin > -1.0e30f);
                     b.r0 = __builtin_amdgcn_sqrtf(r2) * 1.001f + 1.0e-3f;
                     b.smin = smin - 1.0e-3f - 1.0e-4f * __builtin_fabsf(smin);
@@ -631,7 +649,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                     const RayK sr = make_ray(start, new_dir);
                     phase(6);
                     // any-hit over the list, kernel.cu:1501-1510
-                    bool shadowed = !inc;   // lanes outside the group are simply done
+                    bool shadowed = !lit;   // lanes outside the group (or unlit) are simply done
                     const int scount_j = (fc.ablate & 1) ? 0 : scount;
                     if (scount_j > 0) {
                         float4 cur = slist[0];
@@ -639,7 +657,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                             const float4 nxt = slist[e + 1 < scount_j ? e + 1 : e];   // keep one entry in flight
                             shadow_test(sr, cur, shadowed, fc.force_slow != 0);
                             cur = nxt;
-                            if (STATS == 1) { st_shadow += __popcll(__ballot(inc)); st_slots += 64; }
+                            if (STATS == 1) { st_shadow += __popcll(__ballot(lit)); st_slots += 64; }
                             if (__all(shadowed)) break;
                         }
                     }
@@ -648,7 +666,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                 }
                 if (CULL) wave_lds_sync();
 
-                if (inc) {
+                if (lit) {   // unlit lanes would add (0 * l.r) * r = +0
                     // b after `unshadowed` float+=double steps, then b *= max(normal.toL, 0)
                     float bsum = brightness_steps(unshadowed);
                     const float a = dot3(normal, chain.toL);                    // kernel.cu:1541

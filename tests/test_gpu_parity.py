@@ -142,12 +142,14 @@ def test_frame_matches_golden(name, cull, rt, gpu):
     assert (rgba[..., 3] == 1).all()
     assert np.array_equal(packed, g["packed"])
     cnt = g["counters"].tolist()
-    assert stats["hit_pixels"] == cnt[2] and stats["unshadowed"] == cnt[3]
+    assert stats["hit_pixels"] == cnt[2]
     if not cull:
         assert stats["primary_tests"] == cnt[0]          # brute force issues exactly the reference's primary tests
+        assert stats["unshadowed"] == cnt[3]
         assert stats["cull_tests"] == 0
     else:
         assert stats["primary_tests"] <= cnt[0]
+        assert stats["unshadowed"] <= cnt[3]             # lights a surface faces away from are skipped
 
 
 @pytest.mark.parametrize("tile", [8, 16, 32, 64])
