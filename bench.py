@@ -50,8 +50,9 @@ def parse():
     ap.add_argument("--tile", type=int, default=0, help="tile width 8/16/32/64 (0 = library default)")
     ap.add_argument("--no-cull", action="store_true", help="brute-force loops exactly as the reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-band-stride", type=int, default=32,
+    ap.add_argument("--cpu-band-stride", type=int, default=8,
                     help="CPU baseline renders every k-th 8-row band of the frame")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline")
     return ap.parse_args()
 
 
@@ -66,6 +67,7 @@ def cpu_baseline(rt, scene, args, gpu_rgba, gpu_packed):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    cores = min(cores, args.cpu_threads)      # a 1-GPU box's CPU share is 16 cores
     w, h = args.width, args.height
     bands = list(range(0, h, 8 * args.cpu_band_stride))
     rows = 0
@@ -92,6 +94,24 @@ def cpu_baseline(rt, scene, args, gpu_rgba, gpu_packed):
         "tests_per_ray": tests / rays,
         "gpu_vs_cpu_mismatched_pixels": mismatched if gpu_rgba is not None else None,
     }
+
+
+def pmc_traffic(args, world):
+    """HBM bytes per launch of the frame kernel from the committed rocprofv3 PMC
+    passes (profiles/*_pmc_summary.json; FETCH_SIZE x2 + WRITE_SIZE as
+    MI355X_MICROARCH.md prescribes). bench.py cannot collect counters itself;
+    the number applies to the default C3 single-GPU configuration only."""
+    if world != 1 or (args.width, args.height, args.spheres, args.spp) != (3840, 2160, 1024, 1) or args.no_cull:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return json.load(f)["derived"].get("hbm_traffic_bytes")
+    except Exception:
+        return None
 
 
 def main():
@@ -182,7 +202,8 @@ def main():
                        "outputs": "float4 RGBA + packed 0x00RRGGBB in HBM"},
             "kernel_ms": kernel_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, world),
+                         "algorithmic_bytes_per_launch": band_bytes,
                          "note": "HBM is NOT the binding roof for this path (SURVEY.md F2); see roofline_valu"},
             "roofline_valu": {"bound": "valu_fp32", "achieved": valu_tflops, "peak": VALU_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": valu_tflops / VALU_PEAK_TFLOPS,

@@ -16,8 +16,10 @@
                                // lists beyond it fall back to the whole table (never seen at C2-C5)
 #endif
 #ifndef RT_MIN_WAVES_PER_SIMD
-#define RT_MIN_WAVES_PER_SIMD 6 // __launch_bounds__ second argument: register budget 512/this
-                               // (measured at C3: 4 -> 3.03 ms, 6 -> 2.74 ms, 8 -> 2.82 ms)
+#define RT_MIN_WAVES_PER_SIMD 5 // __launch_bounds__ second argument: register budget 512/this.
+                               // Measured at C3: 4 -> 1.59 ms; 5 -> 1.45 ms with no spill traffic
+                               // (HBM writes = the 166 MB of pixels); 6 -> 1.43 ms but spills
+                               // that add 0.6 GB of scratch writes per frame.
 #endif
 #define RT_WAVES_PER_WG 4
 

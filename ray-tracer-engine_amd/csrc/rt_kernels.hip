@@ -465,9 +465,9 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
         phase(2);
 
         const bool hit = valid && (nt != __builtin_inff());   // kernel.cu:1374
-        float cr, cg, cb;   // this sample's colour
 
         // ================= miss: skybox::getFColor, kernel.cu:1147-1166 =================
+        int sky_idx = -1;
         if (valid && !hit) {
             const float4 sk = make_float4(fc.sky_cx, fc.sky_cy, fc.sky_cz, fc.sky_r2);
             const Quad q = quadratic(pr, sk);
@@ -481,9 +481,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
             int idx = iy * fc.sky_w + ix;
             const int last = fc.sky_w * fc.sky_h - 1;
             idx = idx < 0 ? 0 : (idx > last ? last : idx);   // documented clamp (reference is UB there)
-            cr = fc.sky_r[idx];
-            cg = fc.sky_g[idx];
-            cb = fc.sky_b[idx];
+            sky_idx = idx;
         }
 
         // ================= hit: shade, kernel.cu:1396-1405, 1643-1677 =================
@@ -514,7 +512,12 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
         }
 
         phase(3);
-        float fr = 0.f, fg = 0.f, fb = 0.f;
+        float fr = 0.f, fg = 0.f, fb = 0.f;   // this sample's colour (sky texel on a miss)
+        if (sky_idx >= 0) {
+            fr = fc.sky_r[sky_idx];
+            fg = fc.sky_g[sky_idx];
+            fb = fc.sky_b[sky_idx];
+        }
         if (__any(hit) && !(fc.ablate & 16)) {
             // A tile that straddles a silhouette sees several spheres at different
             // depths; one beam around all of their shadow rays would be fat and its
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                         const float re = __builtin_amdgcn_rsqf(ex * ex + ey * ey + ez * ez);
                         const float dte = (toL.x * ex + toL.y * ey + toL.z * ez) * re;
                         const float angle = __cosf(2.f * dte);
-#pragma unroll
+#pragma unroll 1   // rolled: the unrolled form keeps 30 table values live in VGPRs
                         for (int j = 0; j < RT_SHADOW_SAMPLES; ++j) {
                             const float z = fc.jf[j] * (1.f - angle) + angle;
                             const float sq = __builtin_amdgcn_sqrtf(__builtin_fmaxf(1.f - z * z, 0.f));
@@ -679,11 +682,10 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
             }
             }   // groups
         }
-        if (hit) { cr = fr; cg = fg; cb = fb; }
         if (valid) {
-            acc_r = acc_r + cr;
-            acc_g = acc_g + cg;
-            acc_b = acc_b + cb;
+            acc_r = acc_r + fr;
+            acc_g = acc_g + fg;
+            acc_b = acc_b + fb;
         }
     }
 
