@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--cpu-band-stride", type=int, default=8,
                     help="CPU baseline renders every k-th 8-row band of the frame")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL over xGMI) for real runs; gloo + --share-gpu only to rehearse the "
+                         "N>1 code path on a box with fewer GPUs than ranks")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -124,59 +128,105 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the ray-tracing path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"   # gloo rehearsal stages through host memory
 
     rt = rt_amd.load()
     scene = rt.Scene.default(args.spheres, args.seed)
     w, h = args.width, args.height
-    y0, y1 = rt.band_rows(h, rank, world)
-    rows = y1 - y0
     from ray_tracer_engine_amd import distributed as rd
-    max_rows = rd.max_band_rows(h, world)
+    BLOCK = 16
+    if world > 1:
+        # balanced split: 16-row blocks dealt round-robin (contiguous bands leave the
+        # sky-heavy ranks idle: 0.36 vs 0.28 ms at N=8), compact band-local buffers
+        my_rows = rt.interleaved_rows(h, rank, world, BLOCK)
+        rows = len(my_rows)
+        max_rows = rd.max_interleaved_rows(h, world, BLOCK)
+        interleave = (world, rank, BLOCK)
+        y0 = y1 = 0
+    else:
+        y0, y1 = 0, h
+        rows = max_rows = h
+        interleave = None
 
-    # outputs resident in HBM: float4 linear colour + packed words, band-local
+    # outputs resident in HBM: float4 linear colour + packed words, band-local.
+    # Two packed buffers so that frame i's gather overlaps frame i+1's kernel.
     rgba = torch.empty((rows, w, 4), dtype=torch.float32, device="cuda")
-    packed = rd.alloc_band(h, w, world, "cuda")                             # padded to equal gather counts
-    gathered = [torch.empty_like(packed) for _ in range(world)] if (world > 1 and rank == 0) else None
+    packed2 = [torch.zeros((max_rows, w), dtype=torch.int32, device="cuda") for _ in range(2)]
+    gathered2 = [[torch.empty((max_rows, w), dtype=torch.int32, device=coll_dev) for _ in range(world)]
+                 for _ in range(2)] if (world > 1 and rank == 0) else [None, None]
+    frame = torch.empty((h, w), dtype=torch.int32, device=coll_dev) if (world > 1 and rank == 0) else None
     stream = torch.cuda.current_stream()
-    fd = scene.frame_desc(w, h, pixels=packed.data_ptr(), rgba=rgba.data_ptr(), y0=y0, y1=y1, spp=args.spp,
-                          cull=not args.no_cull, tile=args.tile)
+    fds = [scene.frame_desc(w, h, pixels=p.data_ptr(), rgba=rgba.data_ptr(), y0=y0, y1=y1, spp=args.spp,
+                            cull=not args.no_cull, tile=args.tile, interleave=interleave) for p in packed2]
+    packed = packed2[0]
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    pending = [None, None]
 
-    def step(i=None):
+    def finish(b):
+        """Complete frame b's gather and, on the root, put the rows in place."""
+        if pending[b] is not None:
+            pending[b].wait()
+            pending[b] = None
+            if rank == 0:
+                rd.assemble_interleaved(gathered2[b], h, BLOCK, out=frame)
+
+    def step(k, i=None):
+        b = k & 1
+        if world > 1:
+            finish(b)                      # buffer b is free again
         if i is not None:
             ev[i][0].record(stream)
-        scene.render_raw(fd, stream.cuda_stream)
+        scene.render_raw(fds[b], stream.cuda_stream)
         if i is not None:
             ev[i][1].record(stream)
-        if world > 1:
-            rd.gather_bands(packed, dst=0, out=gathered)      # the frame's single collective
+        if world > 1:                      # the frame's single collective, asynchronous
+            src = packed2[b] if coll_dev == "cuda" else packed2[b].cpu()
+            if rank == 0:
+                pending[b] = dist.gather(src, gathered2[b], dst=0, async_op=True)
+            else:
+                pending[b] = dist.gather(src, None, dst=0, async_op=True)
 
+    k = 0
     for _ in range(args.warmup):
-        step()
+        step(k)
+        k += 1
     if world > 1:
+        finish(0)
+        finish(1)
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(k, i)
+        k += 1
+    if world > 1:
+        finish(k & 1)
+        finish((k + 1) & 1)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    packed = packed2[(k - 1) & 1]
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms_max = float(t[0]), float(t[1])
 
     # executed-work statistics from the instrumented kernel variant (untimed)
-    stats = scene.render(w, h, y0=y0, y1=y1, want_stats=True, spp=args.spp, cull=not args.no_cull, tile=args.tile)["stats"]
-    st = torch.tensor([stats[k] for k in rt.STAT_NAMES], dtype=torch.float64, device="cuda")
+    stats = scene.render(w, h, y0=y0, y1=y1, want_stats=True, spp=args.spp, cull=not args.no_cull, tile=args.tile,
+                         interleave=interleave)["stats"]
+    st = torch.tensor([stats[k] for k in rt.STAT_NAMES], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(st, op=dist.ReduceOp.SUM)
     stats = dict(zip(rt.STAT_NAMES, [float(v) for v in st.cpu()]))
@@ -198,7 +248,8 @@ def main():
             "config": {"workload": f"C3: {w}x{h}, {args.spheres} spheres (MSVC rand() replay seed {args.seed}), "
                                    f"{args.spp} spp, 3 lights x 10 shadow samples, LDS sphere-tile staging on",
                        "cull": not args.no_cull, "tile": args.tile or 8,
-                       "parallelism": f"row-bands x{world} + 1 RCCL gather" if world > 1 else "single GPU",
+                       "parallelism": f"{BLOCK}-row blocks round-robin x{world} + 1 RCCL gather per frame "
+                                      f"(overlapped with the next frame's kernel)" if world > 1 else "single GPU",
                        "outputs": "float4 RGBA + packed 0x00RRGGBB in HBM"},
             "kernel_ms": kernel_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -225,6 +276,10 @@ def main():
             out["work"]["brute_force_tests_per_ray"] = cb["tests_per_ray"]
             out["work"]["algorithmic_rate_TFLOPs"] = brute_tests * FLOP_PER_TEST / (kernel_ms * 1e-3) / 1e12
             out["work"]["executed_over_brute_force"] = slots / brute_tests
+        if world > 1:
+            idx = torch.as_tensor(my_rows, device=frame.device)
+            out["gathered_frame_shape"] = list(frame.shape)
+            out["gathered_rank0_rows_ok"] = bool(torch.equal(frame[idx], packed[:rows].to(frame.device)))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -135,6 +135,13 @@ typedef struct rt_launch_opts {
     int force_slow_path;     /* testing: disable every exactness-preserving shortcut  */
     int profile;             /* diagnostics: with `stats`, fill the per-phase cycle
                                 counters (RT_STAT_PHASE0..) instead of work counters   */
+    int interleave_count;    /* multi-GPU load balance: when > 1 this call renders the
+                                row blocks k = interleave_index, +count, +2*count, ... of
+                                `interleave_rows` rows each (y0/y1 must be 0). Output
+                                buffers are compact: local row L holds global row
+                                ((L / rows) * count + index) * rows + L % rows          */
+    int interleave_index;
+    int interleave_rows;     /* block height, a multiple of 16; 0 = 16                 */
 } rt_launch_opts;
 
 enum { RT_STAT_PRIMARY_TESTS = 0, /* sphere tests issued for primary rays (per lane) */

@@ -92,7 +92,8 @@ class LaunchOpts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("rgba", C.c_void_p), ("y0", C.c_int), ("y1", C.c_int),
                 ("spp", C.c_int), ("sample_base", C.c_int), ("sample_total", C.c_int),
                 ("accumulate", C.c_int), ("resolve", C.c_int), ("cull", C.c_int), ("tile", C.c_int),
-                ("stats", C.c_void_p), ("force_slow_path", C.c_int), ("profile", C.c_int)]
+                ("stats", C.c_void_p), ("force_slow_path", C.c_int), ("profile", C.c_int),
+                ("interleave_count", C.c_int), ("interleave_index", C.c_int), ("interleave_rows", C.c_int)]
 
 
 class FrameDesc(C.Structure):
@@ -230,6 +231,17 @@ def band_rows(height: int, rank: int, world: int):
     return y0, y0 + base + (1 if rank < rem else 0)
 
 
+def interleaved_rows(height: int, rank: int, world: int, block: int = 16):
+    """Global row indices owned by `rank` when row blocks of `block` rows are dealt
+    round-robin over `world` ranks (balanced multi-GPU split), in local-row order."""
+    rows = []
+    k = rank
+    while k * block < height:
+        rows.extend(range(k * block, min((k + 1) * block, height)))
+        k += world
+    return rows
+
+
 class Scene:
     """Device-resident scene (rt_scene). Keeps the host arrays it was built from
     so tests can hand exactly the same inputs to the oracle."""
@@ -289,7 +301,7 @@ class Scene:
 
     def frame_desc(self, width, height, *, pixels=0, rgba=0, cam=None, aspect=None, y0=0, y1=0, spp=1,
                    sample_base=0, sample_total=0, accumulate=False, resolve=0, cull=True, tile=0,
-                   stats=0, force_slow=False, profile=False) -> FrameDesc:
+                   stats=0, force_slow=False, profile=False, interleave=None) -> FrameDesc:
         fd = FrameDesc()
         fd.struct_size = C.sizeof(FrameDesc)
         fd.width, fd.height = width, height
@@ -308,6 +320,8 @@ class Scene:
         o.stats = stats
         o.force_slow_path = 1 if force_slow else 0
         o.profile = 1 if profile else 0
+        if interleave is not None:          # (count, index, block_rows)
+            o.interleave_count, o.interleave_index, o.interleave_rows = interleave
         return fd
 
     def render_raw(self, fd: FrameDesc, stream=0):
@@ -320,6 +334,9 @@ class Scene:
         if not torch.cuda.is_available():
             raise RtError("no GPU visible: the ray-tracing path has no CPU fallback")
         rows = (y1 if y1 else height) - y0
+        if kw.get("interleave") is not None:
+            cnt, idx, blk = kw["interleave"]
+            rows = len(interleaved_rows(height, idx, cnt, blk or 16))
         packed = torch.empty((rows, width), dtype=torch.int32, device="cuda")
         rgba = torch.empty((rows, width, 4), dtype=torch.float32, device="cuda") if want_rgba else None
         stats = torch.zeros(RT_STATS_COUNT, dtype=torch.int64, device="cuda") if want_stats else None

@@ -48,6 +48,8 @@ struct RtFrameConsts {
     int accumulate, resolve;
     int force_slow;
     int ablate;                 // diagnostics only (RT_ABLATE env): skip parts of the kernel to price them
+    int il_count, il_index, il_rows;   // interleaved row blocks (multi-GPU); il_count <= 1: contiguous band
+    int local_rows;             // rows rendered by this launch (= y1 - y0 for a contiguous band)
 
     // primary-ray uniforms (kernel.cu:1624-1631, 248-258)
     double aspect_d;            // (double)aspect

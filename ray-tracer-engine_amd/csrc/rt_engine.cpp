@@ -303,9 +303,16 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
         rt_set_error("rt_scene_render: scene has no skybox");
         return RT_ERR_INVALID;
     }
-    if (!fd->pixels && !o.rgba) {
-        rt_set_error("rt_scene_render: no output buffer (pixels and opts.rgba are both null)");
-        return RT_ERR_INVALID;
+    {
+        bool owns_rows = true;
+        if (o.interleave_count > 1) {
+            const int b = o.interleave_rows > 0 ? o.interleave_rows : 16;
+            owns_rows = b > 0 && (long long)o.interleave_index * b < fd->height;
+        }
+        if (owns_rows && !fd->pixels && !o.rgba) {
+            rt_set_error("rt_scene_render: no output buffer (pixels and opts.rgba are both null)");
+            return RT_ERR_INVALID;
+        }
     }
 
     memset(fc, 0, sizeof *fc);
@@ -320,6 +327,23 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
     fc->sample_total = (float)total;
     fc->accumulate = o.accumulate ? 1 : 0;
     fc->resolve = (fd->pixels && o.resolve >= 0) ? 1 : 0;
+    fc->local_rows = y1 - y0;
+    if (o.interleave_count > 1) {
+        const int b = o.interleave_rows > 0 ? o.interleave_rows : 16;
+        if (o.y0 != 0 || (o.y1 != 0 && o.y1 != fd->height) || b % 16 != 0 || o.interleave_index < 0 ||
+            o.interleave_index >= o.interleave_count) {
+            rt_set_error("rt_scene_render: bad interleave (count=%d index=%d rows=%d; y0/y1 must be 0)",
+                         o.interleave_count, o.interleave_index, b);
+            return RT_ERR_INVALID;
+        }
+        fc->il_count = o.interleave_count;
+        fc->il_index = o.interleave_index;
+        fc->il_rows = b;
+        int rows = 0;   // rows of the blocks this rank owns
+        for (int k = o.interleave_index; k * b < fd->height; k += o.interleave_count)
+            rows += (fd->height - k * b < b) ? fd->height - k * b : b;
+        fc->local_rows = rows;   // may be 0 (more ranks than row blocks): the launch is then skipped
+    }
     fc->force_slow = o.force_slow_path ? 1 : 0;
     {   // timing experiments only: output is wrong when set
         const char *ab = getenv("RT_ABLATE");
@@ -413,6 +437,7 @@ extern "C" int rt_scene_render(rt_scene *s, const rt_frame_desc *fd, void *strea
     int tile = 8;
     rc = tile_from_opts(fd->opts, &tile);
     if (rc != RT_OK) return rc;
+    if (fc.local_rows == 0) return RT_OK;   // this rank owns no rows of the frame
     const int cull = (fd->opts.cull == 0) ? 0 : 1;
     const int stats = fd->opts.stats ? (fd->opts.profile ? 2 : 1) : 0;
     RT_HIP(rt_dev_launch_trace(&fc, s->d_spheres, tile, cull, stats, (hipStream_t)stream));

@@ -358,10 +358,14 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
     float4 *mylist = lds + n_pad + wave * RT_LIST_CAP;
 
     const int tile_x = (blockIdx.x * WGX + (wave % WGX)) * TW;
-    const int tile_y = fc.y0 + (blockIdx.y * (RT_WAVES_PER_WG / WGX) + (wave / WGX)) * TH;
+    // local row -> global row: a contiguous band, or row blocks dealt round-robin
+    // to the ranks of a multi-GPU frame (il_rows is a multiple of the tile rows a
+    // workgroup covers, so a tile never straddles two blocks)
+    const int ly = (blockIdx.y * (RT_WAVES_PER_WG / WGX) + (wave / WGX)) * TH + (lane / TW);
     const int px = tile_x + (lane % TW);
-    const int py = tile_y + (lane / TW);
-    const bool valid = (px < fc.width) && (py < fc.y1);
+    const int py = (fc.il_count > 1) ? ((ly / fc.il_rows) * fc.il_count + fc.il_index) * fc.il_rows + (ly % fc.il_rows)
+                                     : fc.y0 + ly;
+    const bool valid = (px < fc.width) && (ly < fc.local_rows) && (py < fc.y1);
     if (!__any(valid)) return;   // wave-uniform; after the only workgroup barrier
 
     unsigned long long st_primary = 0, st_shadow = 0, st_cull = 0, st_slots = 0, st_entries = 0,
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
 
     // ================= write-back =================
     if (valid) {
-        const size_t o = (size_t)(py - fc.y0) * (size_t)fc.width + (size_t)px;
+        const size_t o = (size_t)ly * (size_t)fc.width + (size_t)px;
         float w = (float)fc.spp;
         if (fc.rgba) {
             float4 *dst = reinterpret_cast<float4 *>(fc.rgba) + o;
@@ -837,7 +841,7 @@ extern "C" hipError_t rt_dev_launch_trace(const RtFrameConsts *fc, const float4 
 {
     const int n_pad = (fc->n_spheres + 63) & ~63;
     const size_t lds_bytes = (size_t)(n_pad + RT_WAVES_PER_WG * RT_LIST_CAP) * sizeof(float4);
-    const int band_h = fc->y1 - fc->y0;
+    const int band_h = fc->local_rows;
     const int th = 64 / tile_w;
     const int wgx = (tile_w <= 16) ? 2 : 1;
     const int wgy = RT_WAVES_PER_WG / wgx;

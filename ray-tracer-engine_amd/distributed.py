@@ -11,7 +11,7 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
-from . import band_rows
+from . import band_rows, interleaved_rows
 
 
 def max_band_rows(height: int, world: int) -> int:
@@ -46,3 +46,25 @@ def assemble_frame(gathered, height: int) -> torch.Tensor:
         y0, y1 = band_rows(height, r, world)
         parts.append(g[: y1 - y0])
     return torch.cat(parts, dim=0)
+
+
+# --- balanced variant: row blocks dealt round-robin (rt_launch_opts.interleave_*) ---
+def max_interleaved_rows(height: int, world: int, block: int = 16) -> int:
+    return max(len(interleaved_rows(height, r, world, block)) for r in range(world))
+
+
+def alloc_interleaved(height: int, width: int, world: int, device, block: int = 16, dtype=torch.int32):
+    return torch.zeros((max_interleaved_rows(height, world, block), width), dtype=dtype, device=device)
+
+
+def assemble_interleaved(gathered, height: int, block: int = 16, out=None) -> torch.Tensor:
+    """Scatter each rank's compact rows back to their global rows (one indexed
+    copy per rank on the root GPU)."""
+    world = len(gathered)
+    width = gathered[0].shape[1]
+    if out is None:
+        out = torch.empty((height, width), dtype=gathered[0].dtype, device=gathered[0].device)
+    for r, g in enumerate(gathered):
+        idx = torch.as_tensor(interleaved_rows(height, r, world, block), device=g.device)
+        out.index_copy_(0, idx, g[: idx.numel()])
+    return out

@@ -49,6 +49,40 @@ def _worker(rank, world, port, w, h, n, out_path):
     dist.destroy_process_group()
 
 
+def _worker_interleaved(rank, world, port, w, h, out_path):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rt_amd
+    rt = rt_amd.load()
+    from ray_tracer_engine_amd import distributed as rd
+    rows = rt.interleaved_rows(h, rank, world, 16)
+    band = rd.alloc_interleaved(h, w, world, "cpu")
+    # stand-in band content: every pixel encodes its GLOBAL row and column
+    gy = torch.tensor(rows, dtype=torch.int32).unsqueeze(1)
+    band[: len(rows)] = gy * 65536 + torch.arange(w, dtype=torch.int32).unsqueeze(0)
+    got = rd.gather_bands(band, dst=0)
+    if rank == 0:
+        np.save(out_path, rd.assemble_interleaved(got, h, 16).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,h", [(2, 90), (3, 100)])
+def test_interleaved_gather_scatters_rows_home(world, h, tmp_path, rt):
+    w = 40
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker_interleaved, args=(world, _free_port(), w, h, out), nprocs=world, join=True)
+    frame = np.load(out)
+    want = np.arange(h, dtype=np.int32)[:, None] * 65536 + np.arange(w, dtype=np.int32)[None, :]
+    assert np.array_equal(frame, want)
+    # every row owned exactly once, sizes differ by at most one block
+    owned = sorted(sum((rt.interleaved_rows(h, r, world, 16) for r in range(world)), []))
+    assert owned == list(range(h))
+
+
 @pytest.mark.parametrize("world,h", [(2, 54), (3, 53)])
 def test_band_gather_reassembles_frame(world, h, tmp_path, rt, oracle):
     from scenes import Inputs
