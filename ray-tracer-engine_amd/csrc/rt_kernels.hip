@@ -40,24 +40,34 @@ struct V3 {
 // ---------------------------------------------------------------------------
 // wave64 helpers
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float wave_max(float v)
+// Wave-wide reductions on the VALU's DPP path (no LDS round trips): butterfly
+// inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 carry the row
+// results upward so that lane 63 holds the reduction, which is broadcast back
+// through an SGPR. All 64 lanes must be active (callers are in uniform control flow).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
+                                                                  CTRL, ROW_MASK, 0xf, false));
 }
-__device__ __forceinline__ float wave_min(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float wave_sum(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+#define RT_WAVE_REDUCE(NAME, OP)                                                   \
+    __device__ __forceinline__ float NAME(float v)                                 \
+    {                                                                              \
+        v = OP(v, dpp_move<0xB1, 0xf>(v));  /* quad_perm [1,0,3,2]  */              \
+        v = OP(v, dpp_move<0x4E, 0xf>(v));  /* quad_perm [2,3,0,1]  */              \
+        v = OP(v, dpp_move<0x141, 0xf>(v)); /* row_half_mirror      */              \
+        v = OP(v, dpp_move<0x140, 0xf>(v)); /* row_mirror           */              \
+        v = OP(v, dpp_move<0x142, 0xa>(v)); /* row_bcast:15 -> rows 1,3 */          \
+        v = OP(v, dpp_move<0x143, 0xc>(v)); /* row_bcast:31 -> rows 2,3 */          \
+        return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); \
+    }
+__device__ __forceinline__ float rt_fmax(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ float rt_fmin(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float rt_fadd(float a, float b) { return a + b; }
+RT_WAVE_REDUCE(wave_max, rt_fmax)
+RT_WAVE_REDUCE(wave_min, rt_fmin)
+RT_WAVE_REDUCE(wave_sum, rt_fadd)
+#undef RT_WAVE_REDUCE
 __device__ __forceinline__ float uniform(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
