@@ -30,6 +30,8 @@ extern "C" {
 #define RT_ABI_VERSION 1
 #define RT_MAX_LIGHTS 8      /* reference uses light_size = 3 (kernel.cu:1692) */
 #define RT_MAX_SPP 16
+#define RT_MAX_PLANES 64    /* planes and cubes are tested exhaustively (no culling) */
+#define RT_MAX_CUBES 256
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -68,6 +70,22 @@ typedef struct rt_sphere {                                   /* sphere : shape, 
     uint32_t tail_pad_;
 } rt_sphere;                                                 /* 32 bytes */
 
+typedef struct rt_plane {                                    /* plane : shape, kernel.cu:360-384 */
+    void *vptr_slot;
+    rt_vec3 orgin;           /* a point on the plane                                  */
+    uint8_t reflective;
+    uint8_t pad_[3];
+    rt_vec3 normal;          /* used as given (not normalised by the kernel)          */
+    uint32_t tail_pad_;
+} rt_plane;                                                  /* 40 bytes (kernel.cu:1214) */
+
+typedef struct rt_cube {                                     /* cube : shape, kernel.cu:387-509 */
+    void *vptr_slot;
+    rt_vec3 orgin;           /* (c1 + c2) / 2 (ctor, kernel.cu:395)                   */
+    rt_vec3 normals[3];      /* unused by the kernel                                  */
+    rt_vec3 bounds[2];       /* the two corners of the slab test (kernel.cu:457-485)  */
+} rt_cube;                                                   /* 80 bytes */
+
 typedef struct rt_buffer {                                   /* buffer, sprite.h:11-19 */
     float *data;             /* planar floats in [0,1]                                */
     int size;                /* bytes (Sprite.cpp:14)                                 */
@@ -88,8 +106,8 @@ typedef struct rt_object {                                   /* object, kernel.c
     int depth;                                               /* :1232 */
     rt_sphere *s1;           /* host staging copy                                     */
     rt_sphere *d_spheres;    /* what the kernel reads (:1333)                         */
-    void *c1, *d_cubes;      /* cube  -- OUT OF SCOPE: cube_count must be 0            */
-    void *planes, *d_planes; /* plane -- OUT OF SCOPE: plane_count must be 0           */
+    rt_cube *c1, *d_cubes;   /* cubes read by the kernel at kernel.cu:1344-1356, 1526-1536 */
+    rt_plane *planes, *d_planes; /* planes, kernel.cu:1359-1372, 1513-1523            */
     void *mesh1;             /* mesh  -- OUT OF SCOPE: must be NULL (bvhbox_count = 0) */
     rt_sprite *texture;      /* :1240, read at :1643-1655                             */
     void *mat;               /* unused                                                */
@@ -204,6 +222,9 @@ int rt_offscreen_write_ppm(const char *path);     /* dump the presented frame   
 /* ------------------------------------------------------------------ *
  * Scene construction helpers (host side, no GPU needed)               *
  * ------------------------------------------------------------------ */
+/* plane(pos, normal) (kernel.cu:364-367) and cube(c1, c2) (kernel.cu:391-396). */
+void rt_plane_init(rt_plane *p, float px, float py, float pz, float nx, float ny, float nz);
+void rt_cube_init(rt_cube *c, float ax, float ay, float az, float bx, float by, float bz);
 /* sphere::sphere(org, r) (kernel.cu:285-288): stores radius = r*r.     */
 void rt_sphere_init(rt_sphere *s, float x, float y, float z, float r);
 /* The scene of object::loadMesh (kernel.cu:1189-1192) with the MSVC rand()
@@ -232,6 +253,8 @@ typedef struct rt_scene rt_scene;    /* opaque, device-resident copy of one scen
 rt_scene *rt_scene_create(void);
 void rt_scene_destroy(rt_scene *s);
 int rt_scene_set_spheres(rt_scene *s, const rt_sphere *host_spheres, int n);
+int rt_scene_set_planes(rt_scene *s, const rt_plane *host_planes, int n);   /* SURVEY.md 8(f) row 2 */
+int rt_scene_set_cubes(rt_scene *s, const rt_cube *host_cubes, int n);
 int rt_scene_set_texture(rt_scene *s, const float *r, const float *g, const float *b, int w, int h);
 int rt_scene_set_sky(rt_scene *s, const rt_sphere *box, const float *r, const float *g,
                      const float *b, int w, int h);

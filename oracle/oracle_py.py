@@ -34,6 +34,14 @@ class OSphere(C.Structure):
     _fields_ = [("vptr", C.c_void_p), ("orgin", OVec3), ("reflective", C.c_ubyte), ("radius", C.c_float)]
 
 
+class OPlane(C.Structure):
+    _fields_ = [("vptr", C.c_void_p), ("orgin", OVec3), ("reflective", C.c_ubyte), ("normal", OVec3)]
+
+
+class OCube(C.Structure):
+    _fields_ = [("vptr", C.c_void_p), ("orgin", OVec3), ("normals", OVec3 * 3), ("bounds", OVec3 * 2)]
+
+
 class OSprite(C.Structure):
     _fields_ = [("r", C.POINTER(C.c_float)), ("g", C.POINTER(C.c_float)), ("b", C.POINTER(C.c_float)),
                 ("width", C.c_int), ("height", C.c_int)]
@@ -44,7 +52,9 @@ class OFrame(C.Structure):
                 ("spheres", C.POINTER(OSphere)), ("sphere_count", C.c_int),
                 ("texture", C.POINTER(OSprite)), ("lights", C.POINTER(OLight)), ("light_size", C.c_int),
                 ("cam", OCamera), ("sky_box", C.POINTER(OSphere)), ("sky_tex", C.POINTER(OSprite)),
-                ("y0", C.c_int), ("y1", C.c_int), ("off_x", C.c_double), ("off_y", C.c_double)]
+                ("y0", C.c_int), ("y1", C.c_int), ("off_x", C.c_double), ("off_y", C.c_double),
+                ("cubes", C.POINTER(OCube)), ("cube_count", C.c_int),
+                ("planes", C.POINTER(OPlane)), ("plane_count", C.c_int)]
 
 
 _libs = {}
@@ -85,6 +95,14 @@ def load(libm: bool = False):
     lib.oracle_cast_light_ray.argtypes = [C.POINTER(OSphere), ci, C.POINTER(OVec3), C.POINTER(OLight), C.POINTER(OVec3)]
     lib.oracle_light_dirs.restype = None
     lib.oracle_light_dirs.argtypes = [C.POINTER(OVec3), C.POINTER(OLight), C.POINTER(cf)]
+    lib.oracle_plane_intersect.restype = ci
+    lib.oracle_plane_intersect.argtypes = [C.POINTER(OPlane), C.POINTER(ORay), C.POINTER(cf)]
+    lib.oracle_cube_intersect.restype = ci
+    lib.oracle_cube_intersect.argtypes = [C.POINTER(OCube), C.POINTER(ORay), C.POINTER(cf)]
+    lib.oracle_make_plane.restype = None
+    lib.oracle_make_plane.argtypes = [C.POINTER(OPlane)] + [cf] * 6
+    lib.oracle_make_cube.restype = None
+    lib.oracle_make_cube.argtypes = [C.POINTER(OCube)] + [cf] * 6
     lib.oracle_msvc_srand.restype = None
     lib.oracle_msvc_srand.argtypes = [C.c_uint]
     lib.oracle_msvc_rand.restype = ci
@@ -115,7 +133,8 @@ def make_sprite(planes):
 
 
 def render(spheres, n_spheres, texture_planes, sky_planes, sky_box, lights, n_lights, cam, width, height,
-           aspect, y0=0, y1=None, off=(0.5, 0.5), nthreads=1, libm=False, want_rgba=True):
+           aspect, y0=0, y1=None, off=(0.5, 0.5), nthreads=1, libm=False, want_rgba=True,
+           cubes=None, n_cubes=0, planes=None, n_planes=0):
     """Run the oracle on the given inputs. `spheres`/`lights`/`cam`/`sky_box` may be
     the product's ctypes arrays: they are byte-copied into the oracle's own PODs.
     Returns (rgba float32 [rows,W,4], packed uint32 [rows,W], counters dict)."""
@@ -131,8 +150,14 @@ def render(spheres, n_spheres, texture_planes, sky_planes, sky_box, lights, n_li
     C.memmove(C.byref(obox), C.byref(sky_box), 32)
     tex = make_sprite(texture_planes)
     sky = make_sprite(sky_planes)
+    ocubes = (OCube * max(n_cubes, 1))()
+    if n_cubes:
+        C.memmove(ocubes, cubes, 80 * n_cubes)
+    oplanes = (OPlane * max(n_planes, 1))()
+    if n_planes:
+        C.memmove(oplanes, planes, 40 * n_planes)
     fr = OFrame(width, height, aspect, osph, n_spheres, C.pointer(tex), olights, n_lights, ocam,
-                C.pointer(obox), C.pointer(sky), y0, y1, off[0], off[1])
+                C.pointer(obox), C.pointer(sky), y0, y1, off[0], off[1], ocubes, n_cubes, oplanes, n_planes)
     rows = y1 - y0
     rgba = np.zeros((rows, width, 4), dtype=np.float32) if want_rgba else None
     packed = np.zeros((rows, width), dtype=np.uint32)

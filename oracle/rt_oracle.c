@@ -151,6 +151,74 @@ void oracle_make_sphere(o_sphere *s, float x, float y, float z, float r)
     s->radius = r * r; /* kernel.cu:287 */
 }
 
+/* ---- plane::intersect, kernel.cu:370-380 ---- */
+static int plane_intersect(const o_plane *p, const ray *cam_ray, float *t)
+{
+    float denom = dotproduct(&p->normal, &cam_ray->Dir);
+    if (denom < 0) {
+        vec3d pl0 = sub(&p->orgin, &cam_ray->Org);
+        *t = dotproduct(&pl0, &p->normal) / denom;
+        return *t >= 0;
+    }
+    return 0;
+}
+
+/* the reference's min/max are macros (kernel.cu:16-26): (a) > (b) ? (a) : (b) */
+#define O_MAX(a, b) (((a) > (b)) ? (a) : (b))
+#define O_MIN(a, b) (((a) < (b)) ? (a) : (b))
+
+/* ---- cube::intersect, kernel.cu:457-485 (slab test; tmin may be negative) ---- */
+static int cube_intersect(const o_cube *c, const ray *cam_ray, float *t)
+{
+    float dirx = 1.f / cam_ray->Dir.x;
+    float diry = 1.f / cam_ray->Dir.y;
+    float dirz = 1.f / cam_ray->Dir.z;
+
+    float t1 = (c->bounds[0].x - cam_ray->Org.x) * dirx;
+    float t2 = (c->bounds[1].x - cam_ray->Org.x) * dirx;
+
+    float t3 = (c->bounds[0].y - cam_ray->Org.y) * diry;
+    float t4 = (c->bounds[1].y - cam_ray->Org.y) * diry;
+
+    float t5 = (c->bounds[0].z - cam_ray->Org.z) * dirz;
+    float t6 = (c->bounds[1].z - cam_ray->Org.z) * dirz;
+
+    float tmin = O_MAX(O_MAX(O_MIN(t1, t2), O_MIN(t3, t4)), O_MIN(t5, t6));
+    float tmax = O_MIN(O_MIN(O_MAX(t1, t2), O_MAX(t3, t4)), O_MAX(t5, t6));
+
+    if (tmax < 0) {
+        *t = tmax;
+        return 0;
+    }
+    if (tmax < tmin) {
+        *t = tmax;
+        return 0;
+    }
+    *t = tmin;
+    return 1;
+}
+
+int oracle_plane_intersect(const o_plane *p, const o_ray *r, float *t) { return plane_intersect(p, r, t); }
+int oracle_cube_intersect(const o_cube *c, const o_ray *r, float *t) { return cube_intersect(c, r, t); }
+
+void oracle_make_plane(o_plane *p, float px, float py, float pz, float nx, float ny, float nz)
+{
+    memset(p, 0, sizeof *p);                 /* plane(pos, normal), kernel.cu:364-367 */
+    p->orgin.x = px; p->orgin.y = py; p->orgin.z = pz;
+    p->normal.x = nx; p->normal.y = ny; p->normal.z = nz;
+}
+
+void oracle_make_cube(o_cube *c, float ax, float ay, float az, float bx, float by, float bz)
+{
+    memset(c, 0, sizeof *c);                 /* cube(c1, c2), kernel.cu:391-396 */
+    c->bounds[0].x = ax; c->bounds[0].y = ay; c->bounds[0].z = az;
+    c->bounds[1].x = bx; c->bounds[1].y = by; c->bounds[1].z = bz;
+    c->orgin.x = (ax + bx) / 2;              /* divide(add(c1, c2), 2) */
+    c->orgin.y = (ay + by) / 2;
+    c->orgin.z = (az + bz) / 2;
+    c->normals[0].x = 1; c->normals[1].y = 1; c->normals[2].z = 1;   /* kernel.cu:507 */
+}
+
 /* ---- rgbToInt, kernel.cu:547-556 ---- */
 uint32_t oracle_rgb_to_int(int r, int g, int b)
 {
@@ -199,6 +267,7 @@ static int castRay(const ctx_t *cx, const ray *cam_ray, int *hit_index, float *n
                    vec3d *new_org, vec3d *normal, float *tx, float *ty)
 {
     const o_frame *f = cx->f;
+    int hit_type = 1;
     *nt = INFINITY;
 
     for (int i = 0; i < f->sphere_count; i++) {
@@ -208,26 +277,67 @@ static int castRay(const ctx_t *cx, const ray *cam_ray, int *hit_index, float *n
             if (t < *nt) {
                 *nt = t;
                 *hit_index = i;
+                hit_type = 1;
+            }
+        }
+    }
+    /* cubes, kernel.cu:1344-1356 */
+    for (int i = 0; i < f->cube_count; i++) {
+        float t;
+        if (cube_intersect(&f->cubes[i], cam_ray, &t)) {
+            if (t < *nt) {
+                *nt = t;
+                *hit_index = i;
+                hit_type = 3;
+            }
+        }
+    }
+    /* planes, kernel.cu:1359-1372 */
+    for (int i = 0; i < f->plane_count; i++) {
+        float t;
+        if (plane_intersect(&f->planes[i], cam_ray, &t)) {
+            if (t < *nt) {
+                *nt = t;
+                *hit_index = i;
+                hit_type = 2;
             }
         }
     }
 
     if (*nt != INFINITY) {
-        vec3d step = multiplyf(cam_ray->Dir, *nt);
-        *new_org = add(&cam_ray->Org, &step);
-        *normal = sub(new_org, &f->spheres[*hit_index].orgin);
-        *normal = normalise(normal);
-        /* double arithmetic: the literals 1, 3.1415, 0.5 are int/double */
-        *tx = (float)((1 + o_atan2f(normal->z, normal->x) / 3.1415) * 0.5);
-        *ty = (float)(o_acosf(normal->y) / 3.1415);
+        if (hit_type == 1) {            /* kernel.cu:1396-1405 */
+            vec3d step = multiplyf(cam_ray->Dir, *nt);
+            *new_org = add(&cam_ray->Org, &step);
+            *normal = sub(new_org, &f->spheres[*hit_index].orgin);
+            *normal = normalise(normal);
+            /* double arithmetic: the literals 1, 3.1415, 0.5 are int/double */
+            *tx = (float)((1 + o_atan2f(normal->z, normal->x) / 3.1415) * 0.5);
+            *ty = (float)(o_acosf(normal->y) / 3.1415);
+        }
+        if (hit_type == 2) {            /* kernel.cu:1407-1416 */
+            vec3d step = multiplyf(cam_ray->Dir, *nt);
+            *new_org = add(&cam_ray->Org, &step);
+            *normal = f->planes[*hit_index].normal;
+            *tx = (float)0.5;
+            *ty = (float)0.5;
+        }
+        if (hit_type == 3) {            /* kernel.cu:1418-1425 */
+            vec3d step = multiplyf(cam_ray->Dir, *nt);
+            *new_org = add(&cam_ray->Org, &step);
+            *normal = sub(new_org, &f->cubes[*hit_index].orgin);
+            *normal = normalise(normal);
+            *tx = (float)((1 + o_atan2f(normal->z, normal->x) / 3.1415) * 0.5);
+            *ty = (float)(o_acosf(normal->y) / 3.1415);
+        }
         return 1;
     }
     return 0;
 }
 
 /* ---- castLightRay, sphere branch: kernel.cu:1433-1471, 1499-1510, 1537-1544 ---- */
-static float castLightRay_impl(const o_sphere *spheres, int sphere_count, const vec3d *start,
-                               const o_light *l, const vec3d *normal, counters_t *cnt, float *dirs_out)
+static float castLightRay_impl2(const o_sphere *spheres, int sphere_count, const o_plane *planes, int plane_count,
+                                const o_cube *cubes, int cube_count, const vec3d *start,
+                                const o_light *l, const vec3d *normal, counters_t *cnt, float *dirs_out)
 {
     float b = 0;
     int shadow = 0;
@@ -279,6 +389,22 @@ static float castLightRay_impl(const o_sphere *spheres, int sphere_count, const 
                     break;
                 }
             }
+        if (!shadow) /* planes, kernel.cu:1511-1523 */
+            for (int i = 0; i < plane_count; i++) {
+                float t;
+                if (plane_intersect(&planes[i], &light_ray, &t)) {
+                    shadow = 1;
+                    break;
+                }
+            }
+        if (!shadow) /* cubes, kernel.cu:1524-1536 */
+            for (int i = 0; i < cube_count; i++) {
+                float t;
+                if (cube_intersect(&cubes[i], &light_ray, &t)) {
+                    shadow = 1;
+                    break;
+                }
+            }
         if (!shadow) {
             b = (float)(b + 0.1); /* float += double literal */
             if (cnt) cnt->unshadowed++;
@@ -289,10 +415,10 @@ static float castLightRay_impl(const o_sphere *spheres, int sphere_count, const 
     return b;
 }
 
-static float castLightRay(const o_sphere *spheres, int sphere_count, const vec3d *start,
-                          const o_light *l, const vec3d *normal, counters_t *cnt)
+static float castLightRay_impl(const o_sphere *spheres, int sphere_count, const vec3d *start,
+                               const o_light *l, const vec3d *normal, counters_t *cnt, float *dirs_out)
 {
-    return castLightRay_impl(spheres, sphere_count, start, l, normal, cnt, NULL);
+    return castLightRay_impl2(spheres, sphere_count, NULL, 0, NULL, 0, start, l, normal, cnt, dirs_out);
 }
 
 float oracle_cast_light_ray(const o_sphere *spheres, int n, const o_vec3d *start,
@@ -404,8 +530,9 @@ static void trace_pixel(const ctx_t *cx, int x, int y, float *rgba, uint32_t *pa
 
         float fr = 0, fg = 0, fb = 0;
         for (int i = 0; i < f->light_size; i++) {
-            float brightness = castLightRay(f->spheres, f->sphere_count, &start_O,
-                                            &f->lights[i], &obj_normal, cx->cnt);
+            float brightness = castLightRay_impl2(f->spheres, f->sphere_count, f->planes, f->plane_count,
+                                                  f->cubes, f->cube_count, &start_O,
+                                                  &f->lights[i], &obj_normal, cx->cnt, NULL);
             fr += brightness * f->lights[i].r * r;
             fg += brightness * f->lights[i].g * g;
             fb += brightness * f->lights[i].b * b;

@@ -37,6 +37,18 @@ typedef struct {                                            /* kernel.cu:265-358
     unsigned char reflective; /* @20 */
     float radius;        /* @24: ALREADY r*r (ctor, kernel.cu:287) */
 } o_sphere;                                                 /* 32 bytes */
+typedef struct {                                            /* plane : shape, kernel.cu:360-384 */
+    void *vptr;
+    o_vec3d orgin;            /* @8  */
+    unsigned char reflective; /* @20 */
+    o_vec3d normal;           /* @24 */
+} o_plane;                                                  /* 40 bytes (kernel.cu:1214: sizeof(float)*10) */
+typedef struct {                                            /* cube : shape, kernel.cu:387-509 */
+    void *vptr;
+    o_vec3d orgin;            /* @8: (c1+c2)/2 */
+    o_vec3d normals[3];       /* @20 */
+    o_vec3d bounds[2];        /* @56 */
+} o_cube;                                                   /* 80 bytes */
 typedef struct {                                            /* sprite.h:25-47 */
     const float *r, *g, *b; /* rBuff/gBuff/bBuff ->data : planar floats in [0,1] */
     int width, height;
@@ -57,6 +69,10 @@ typedef struct {
     double off_x, off_y;      /* sub-pixel sample position; reference = 0.5,0.5
                                  (kernel.cu:1624-1625). Build-defined extension
                                  for the 4-spp config. */
+    const o_cube *cubes;      /* objs.d_cubes  (kernel.cu:1344-1356); SURVEY 8(f) row 2 */
+    int cube_count;
+    const o_plane *planes;    /* objs.d_planes (kernel.cu:1359-1372) */
+    int plane_count;
 } o_frame;
 
 /* counters[0]=primary sphere tests, [1]=shadow sphere tests,
@@ -76,6 +92,10 @@ void oracle_rotate_dir(const o_camera *cam, const o_vec3d *v, float yaw, float p
 float oracle_cast_light_ray(const o_sphere *spheres, int n, const o_vec3d *start,
                             const o_light *l, const o_vec3d *normal);     /* kernel.cu:1433-1544 */
 void oracle_light_dirs(const o_vec3d *start, const o_light *l, float *dirs30);   /* kernel.cu:1442-1468 */
+int oracle_plane_intersect(const o_plane *p, const o_ray *r, float *t);  /* kernel.cu:370-380 */
+int oracle_cube_intersect(const o_cube *c, const o_ray *r, float *t);    /* kernel.cu:400-485 */
+void oracle_make_plane(o_plane *p, float px, float py, float pz, float nx, float ny, float nz); /* :364-367 */
+void oracle_make_cube(o_cube *c, float ax, float ay, float az, float bx, float by, float bz);   /* :391-396 */
 /* MSVC rand() replay + scene generator (kernel.cu:1189-1192). */
 void oracle_msvc_srand(unsigned int seed);
 int oracle_msvc_rand(void);

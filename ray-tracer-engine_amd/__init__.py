@@ -67,6 +67,15 @@ class Sphere(C.Structure):
                 ("pad_", C.c_uint8 * 3), ("radius", C.c_float), ("tail_pad_", C.c_uint32)]
 
 
+class Plane(C.Structure):
+    _fields_ = [("vptr_slot", C.c_void_p), ("orgin", Vec3), ("reflective", C.c_uint8), ("pad_", C.c_uint8 * 3),
+                ("normal", Vec3), ("tail_pad_", C.c_uint32)]
+
+
+class Cube(C.Structure):
+    _fields_ = [("vptr_slot", C.c_void_p), ("orgin", Vec3), ("normals", Vec3 * 3), ("bounds", Vec3 * 2)]
+
+
 class Buffer(C.Structure):
     _fields_ = [("data", C.POINTER(C.c_float)), ("size", C.c_int)]
 
@@ -83,8 +92,8 @@ class Skybox(C.Structure):
 class Object(C.Structure):
     _fields_ = [("sphere_count", C.c_int), ("plane_count", C.c_int), ("cube_count", C.c_int),
                 ("depth", C.c_int), ("s1", C.POINTER(Sphere)), ("d_spheres", C.POINTER(Sphere)),
-                ("c1", C.c_void_p), ("d_cubes", C.c_void_p), ("planes", C.c_void_p),
-                ("d_planes", C.c_void_p), ("mesh1", C.c_void_p), ("texture", C.POINTER(Sprite)),
+                ("c1", C.POINTER(Cube)), ("d_cubes", C.POINTER(Cube)), ("planes", C.POINTER(Plane)),
+                ("d_planes", C.POINTER(Plane)), ("mesh1", C.c_void_p), ("texture", C.POINTER(Sprite)),
                 ("mat", C.c_void_p), ("tot_mesh", C.c_void_p), ("meshes", C.c_int)]
 
 
@@ -144,6 +153,10 @@ def load_library():
         "rt_offscreen_write_ppm": (ci, [C.c_char_p]),
         "rt_sphere_init": (None, [C.POINTER(Sphere), cf, cf, cf, cf]),
         "rt_generate_spheres": (ci, [C.POINTER(Sphere), ci, C.c_uint]),
+        "rt_plane_init": (None, [C.POINTER(Plane), cf, cf, cf, cf, cf, cf]),
+        "rt_cube_init": (None, [C.POINTER(Cube), cf, cf, cf, cf, cf, cf]),
+        "rt_scene_set_planes": (ci, [vp, C.POINTER(Plane), ci]),
+        "rt_scene_set_cubes": (ci, [vp, C.POINTER(Cube), ci]),
         "rt_msvc_rand_sequence": (ci, [C.c_uint, C.POINTER(ci), ci]),
         "rt_synth_texture_size": (ci, [ci, C.POINTER(ci), C.POINTER(ci)]),
         "rt_synth_texture": (ci, [ci, fp, fp, fp]),
@@ -258,6 +271,8 @@ class Scene:
         self.sky_box = None
         self.lights = None
         self.n_lights = 0
+        self.planes, self.n_planes = None, 0
+        self.cubes, self.n_cubes = None, 0
 
     def close(self):
         if self.handle:
@@ -273,6 +288,14 @@ class Scene:
     def set_spheres(self, spheres, n):
         _check(self.lib.rt_scene_set_spheres(self.handle, spheres, n), "rt_scene_set_spheres")
         self.spheres, self.n_spheres = spheres, n
+
+    def set_planes(self, planes, n):
+        _check(self.lib.rt_scene_set_planes(self.handle, planes, n), "rt_scene_set_planes")
+        self.planes, self.n_planes = planes, n
+
+    def set_cubes(self, cubes, n):
+        _check(self.lib.rt_scene_set_cubes(self.handle, cubes, n), "rt_scene_set_cubes")
+        self.cubes, self.n_cubes = cubes, n
 
     def set_texture(self, planes):
         planes = [np.ascontiguousarray(p, dtype=np.float32) for p in planes]

@@ -37,6 +37,13 @@ struct RtLightDev {
     float pad_;
 };
 
+struct RtPlaneDev {     // plane: a point and the normal as given (kernel.cu:364-367)
+    float ox, oy, oz, nx, ny, nz, pad0_, pad1_;
+};
+struct RtCubeDev {      // cube: the two corners and (c1+c2)/2 (kernel.cu:391-396)
+    float ax, ay, az, bx, by, bz, cx, cy, cz, pad0_, pad1_, pad2_;
+};
+
 struct RtFrameConsts {
     // frame / band geometry
     int width, height;          // full frame (ray generation uses these)
@@ -75,6 +82,11 @@ struct RtFrameConsts {
     const float *sky_r, *sky_g, *sky_b;
     int sky_w, sky_h;
     float sky_cx, sky_cy, sky_cz, sky_r2;   // skybox sphere centre, radius*radius
+
+    // cubes and planes: few, tested exhaustively
+    const RtPlaneDev *planes;
+    const RtCubeDev *cubes;
+    int n_planes, n_cubes;
 
     // outputs
     float *rgba;                // float4 per pixel, band-local, may be null

@@ -118,6 +118,9 @@ struct rt_scene {
     bool have_sky = false;
     rt_light lights[RT_MAX_LIGHTS];
     int n_lights = 0;
+    RtPlaneDev *d_planes = nullptr;
+    RtCubeDev *d_cubes = nullptr;
+    int n_planes = 0, n_cubes = 0;
 };
 
 static const int kMaxSpheresLds = (160 * 1024 - RT_WAVES_PER_WG * RT_LIST_CAP * 16) / 16;
@@ -139,6 +142,8 @@ extern "C" void rt_scene_destroy(rt_scene *s)
     if (s->h_stage) (void)hipHostFree(s->h_stage);
     free_planes(s->d_tex);
     free_planes(s->d_sky);
+    if (s->d_planes) (void)hipFree(s->d_planes);
+    if (s->d_cubes) (void)hipFree(s->d_cubes);
     delete s;
 }
 
@@ -187,6 +192,48 @@ extern "C" int rt_scene_set_spheres(rt_scene *s, const rt_sphere *host_spheres, 
     const int rc = rt_scene_set_spheres_async(s, host_spheres, n, nullptr);
     if (rc != RT_OK) return rc;
     RT_HIP(hipStreamSynchronize(nullptr));
+    return RT_OK;
+}
+
+extern "C" int rt_scene_set_planes(rt_scene *s, const rt_plane *host_planes, int n)
+{
+    if (!s || n < 0 || (n > 0 && !host_planes)) {
+        rt_set_error("rt_scene_set_planes: invalid argument");
+        return RT_ERR_INVALID;
+    }
+    if (n > RT_MAX_PLANES) {
+        rt_set_error("rt_scene_set_planes: %d planes > RT_MAX_PLANES %d", n, RT_MAX_PLANES);
+        return RT_ERR_CAPACITY;
+    }
+    if (!s->d_planes) RT_HIP(hipMalloc((void **)&s->d_planes, sizeof(RtPlaneDev) * RT_MAX_PLANES));
+    std::vector<RtPlaneDev> tmp(n ? n : 1);
+    for (int i = 0; i < n; ++i)
+        tmp[i] = RtPlaneDev{host_planes[i].orgin.x, host_planes[i].orgin.y, host_planes[i].orgin.z,
+                            host_planes[i].normal.x, host_planes[i].normal.y, host_planes[i].normal.z, 0.f, 0.f};
+    if (n) RT_HIP(hipMemcpy(s->d_planes, tmp.data(), sizeof(RtPlaneDev) * n, hipMemcpyHostToDevice));
+    s->n_planes = n;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_set_cubes(rt_scene *s, const rt_cube *host_cubes, int n)
+{
+    if (!s || n < 0 || (n > 0 && !host_cubes)) {
+        rt_set_error("rt_scene_set_cubes: invalid argument");
+        return RT_ERR_INVALID;
+    }
+    if (n > RT_MAX_CUBES) {
+        rt_set_error("rt_scene_set_cubes: %d cubes > RT_MAX_CUBES %d", n, RT_MAX_CUBES);
+        return RT_ERR_CAPACITY;
+    }
+    if (!s->d_cubes) RT_HIP(hipMalloc((void **)&s->d_cubes, sizeof(RtCubeDev) * RT_MAX_CUBES));
+    std::vector<RtCubeDev> tmp(n ? n : 1);
+    for (int i = 0; i < n; ++i) {
+        const rt_cube &c = host_cubes[i];
+        tmp[i] = RtCubeDev{c.bounds[0].x, c.bounds[0].y, c.bounds[0].z, c.bounds[1].x, c.bounds[1].y, c.bounds[1].z,
+                           c.orgin.x, c.orgin.y, c.orgin.z, 0.f, 0.f, 0.f};
+    }
+    if (n) RT_HIP(hipMemcpy(s->d_cubes, tmp.data(), sizeof(RtCubeDev) * n, hipMemcpyHostToDevice));
+    s->n_cubes = n;
     return RT_OK;
 }
 
@@ -295,8 +342,8 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
                      total, RT_MAX_SPP);
         return RT_ERR_INVALID;
     }
-    if (s->n_spheres > 0 && (!s->d_tex[0] || s->tex_w <= 0)) {
-        rt_set_error("rt_scene_render: scene has spheres but no object texture");
+    if ((s->n_spheres > 0 || s->n_planes > 0 || s->n_cubes > 0) && (!s->d_tex[0] || s->tex_w <= 0)) {
+        rt_set_error("rt_scene_render: scene has primitives but no object texture");
         return RT_ERR_INVALID;
     }
     if (!s->have_sky) {
@@ -412,6 +459,10 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
     fc->sky_w = s->sky_w; fc->sky_h = s->sky_h;
     fc->sky_cx = s->sky_c[0]; fc->sky_cy = s->sky_c[1]; fc->sky_cz = s->sky_c[2];
     fc->sky_r2 = s->sky_radius * s->sky_radius;
+    fc->planes = s->d_planes;
+    fc->cubes = s->d_cubes;
+    fc->n_planes = s->n_planes;
+    fc->n_cubes = s->n_cubes;
     fc->rgba = o.rgba;
     fc->packed = fd->pixels;
     fc->stats = (unsigned long long *)o.stats;
@@ -480,11 +531,15 @@ extern "C" int rt_launch_raytrace_ex(uint32_t *pixels, int width, int height, fl
         rt_set_error("rt_launch_raytrace: null objs/lights/sky");
         return RT_ERR_INVALID;
     }
-    // Out-of-scope primitives: the sphere path only.
-    if (objs->cube_count != 0 || objs->plane_count != 0 || objs->mesh1 != nullptr) {
-        rt_set_error("rt_launch_raytrace: cubes/planes/meshes are outside this library's path "
-                     "(cube_count=%d plane_count=%d mesh1=%p)", objs->cube_count, objs->plane_count, objs->mesh1);
+    // Out-of-scope primitive: the triangle mesh / BVH.
+    if (objs->mesh1 != nullptr) {
+        rt_set_error("rt_launch_raytrace: triangle meshes are outside this library's path (mesh1=%p)", objs->mesh1);
         return RT_ERR_UNSUPPORTED;
+    }
+    if (objs->cube_count < 0 || objs->plane_count < 0 || (objs->cube_count > 0 && !objs->d_cubes) ||
+        (objs->plane_count > 0 && !objs->d_planes)) {
+        rt_set_error("rt_launch_raytrace: bad cube/plane list");
+        return RT_ERR_INVALID;
     }
     if (objs->sphere_count < 0 || (objs->sphere_count > 0 && !objs->d_spheres)) {
         rt_set_error("rt_launch_raytrace: bad sphere list");
@@ -494,7 +549,7 @@ extern "C" int rt_launch_raytrace_ex(uint32_t *pixels, int width, int height, fl
         rt_set_error("rt_launch_raytrace: skybox needs a box sphere and a texture");
         return RT_ERR_INVALID;
     }
-    if (objs->sphere_count > 0 && !sprite_ok(objs->texture)) {
+    if ((objs->sphere_count > 0 || objs->cube_count > 0 || objs->plane_count > 0) && !sprite_ok(objs->texture)) {
         rt_set_error("rt_launch_raytrace: object texture missing");
         return RT_ERR_INVALID;
     }
@@ -502,7 +557,7 @@ extern "C" int rt_launch_raytrace_ex(uint32_t *pixels, int width, int height, fl
     rt_scene *s = g_shim.scene;
     int rc;
     // textures: uploaded once per (planes, size); see rt_invalidate_textures()
-    if (objs->sphere_count > 0) {
+    if (objs->sphere_count > 0 || objs->cube_count > 0 || objs->plane_count > 0) {
         const rt_sprite *t = objs->texture;
         if (t->rBuff->data != g_shim.tex_key[0] || t->gBuff->data != g_shim.tex_key[1] ||
             t->bBuff->data != g_shim.tex_key[2] || t->width != g_shim.tex_w || t->height != g_shim.tex_h) {
@@ -531,6 +586,14 @@ extern "C" int rt_launch_raytrace_ex(uint32_t *pixels, int width, int height, fl
     if (rc != RT_OK) return rc;
     rc = rt_scene_set_lights(s, lights, light_size);
     if (rc != RT_OK) return rc;
+    if (objs->plane_count > 0 || s->n_planes > 0) {
+        rc = rt_scene_set_planes(s, objs->d_planes, objs->plane_count);
+        if (rc != RT_OK) return rc;
+    }
+    if (objs->cube_count > 0 || s->n_cubes > 0) {
+        rc = rt_scene_set_cubes(s, objs->d_cubes, objs->cube_count);
+        if (rc != RT_OK) return rc;
+    }
 
     rt_frame_desc fd;
     memset(&fd, 0, sizeof fd);

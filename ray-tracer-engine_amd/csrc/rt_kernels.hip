@@ -193,6 +193,36 @@ __device__ __forceinline__ bool intersect_tail(const RayK &r, const Quad &q, flo
     return false;
 }
 
+// plane::intersect, kernel.cu:370-380
+__device__ __forceinline__ bool plane_intersect(const RtPlaneDev &p, V3 o, V3 d, float &t)
+{
+    const float denom = (p.nx * d.x + p.ny * d.y) + p.nz * d.z;
+    if (denom < 0.f) {
+        const V3 pl0{p.ox - o.x, p.oy - o.y, p.oz - o.z};
+        t = ((pl0.x * p.nx + pl0.y * p.ny) + pl0.z * p.nz) / denom;
+        return t >= 0.f;
+    }
+    return false;
+}
+
+// cube::intersect, kernel.cu:457-485. min/max are the reference's macros
+// (kernel.cu:16-26), whose NaN behaviour differs from fminf/fmaxf. `inv` is
+// 1.f / Dir per component, hoisted out of the per-cube call.
+#define RT_MAXM(a, b) (((a) > (b)) ? (a) : (b))
+#define RT_MINM(a, b) (((a) < (b)) ? (a) : (b))
+__device__ __forceinline__ bool cube_intersect(const RtCubeDev &c, V3 o, V3 inv, float &t)
+{
+    const float t1 = (c.ax - o.x) * inv.x, t2 = (c.bx - o.x) * inv.x;
+    const float t3 = (c.ay - o.y) * inv.y, t4 = (c.by - o.y) * inv.y;
+    const float t5 = (c.az - o.z) * inv.z, t6 = (c.bz - o.z) * inv.z;
+    const float tmin = RT_MAXM(RT_MAXM(RT_MINM(t1, t2), RT_MINM(t3, t4)), RT_MINM(t5, t6));
+    const float tmax = RT_MINM(RT_MINM(RT_MAXM(t1, t2), RT_MAXM(t3, t4)), RT_MAXM(t5, t6));
+    if (tmax < 0.f) { t = tmax; return false; }
+    if (tmax < tmin) { t = tmax; return false; }
+    t = tmin;
+    return true;
+}
+
 // A ray that starts outside a sphere whose centre lies behind it has B > 0 and
 // disc < B*B; then sqrt(disc) < B, t < 0 strictly and intersect() is false. The
 // factor keeps sqrt(disc) below B even after rounding, so the `t == 0` clause
@@ -476,6 +506,30 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
             if (STATS == 1) { st_primary += __popcll(__ballot(valid)); st_slots += 64; }
         }
         if (CULL) wave_lds_sync();   // the list is rebuilt below
+        // cubes (kernel.cu:1344-1356) then planes (:1359-1372): few, tested exhaustively;
+        // for a plane hit hc* carries the plane's normal instead of a centre
+        int hkind = 1;
+        if (fc.n_cubes > 0) {
+            const V3 inv{1.f / D.x, 1.f / D.y, 1.f / D.z};
+            for (int i = 0; i < fc.n_cubes; ++i) {
+                const RtCubeDev c = fc.cubes[i];
+                float t;
+                if (cube_intersect(c, O, inv, t) && t < nt) {
+                    nt = t;
+                    hkind = 3;
+                    hcx = c.cx; hcy = c.cy; hcz = c.cz;
+                }
+            }
+        }
+        for (int i = 0; i < fc.n_planes; ++i) {
+            const RtPlaneDev p = fc.planes[i];
+            float t;
+            if (plane_intersect(p, O, D, t) && t < nt) {
+                nt = t;
+                hkind = 2;
+                hcx = p.nx; hcy = p.ny; hcz = p.nz;
+            }
+        }
         phase(2);
 
         const bool hit = valid && (nt != __builtin_inff());   // kernel.cu:1374
@@ -503,15 +557,19 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
         float tr = 0.f, tg = 0.f, tb = 0.f;
         if (hit) {
             const V3 new_org{O.x + D.x * nt, O.y + D.y * nt, O.z + D.z * nt};
-            normal = V3{new_org.x - hcx, new_org.y - hcy, new_org.z - hcz};
-            normalise_inplace(normal);
-            // tx, ty: the literals 1, 3.1415, 0.5 make these binary64 expressions
-            float tx, ty;
-            if (fc.ablate & 8) {
-                tx = normal.x; ty = normal.y;
-            } else {
-                tx = (float)((1.0 + (double)rtm::atan2f_rt(normal.z, normal.x) / 3.1415) * 0.5);
-                ty = (float)((double)rtm::acosf_rt(normal.y) / 3.1415);
+            float tx = 0.5f, ty = 0.5f;   // plane, kernel.cu:1413-1414
+            if (hkind == 2) {             // plane, kernel.cu:1407-1416: the normal as stored
+                normal = V3{hcx, hcy, hcz};
+            } else {                      // sphere / cube, kernel.cu:1396-1405, 1418-1425
+                normal = V3{new_org.x - hcx, new_org.y - hcy, new_org.z - hcz};
+                normalise_inplace(normal);
+                if (fc.ablate & 8) {
+                    tx = normal.x; ty = normal.y;
+                } else {
+                    // the literals 1, 3.1415, 0.5 make these binary64 expressions
+                    tx = (float)((1.0 + (double)rtm::atan2f_rt(normal.z, normal.x) / 3.1415) * 0.5);
+                    ty = (float)((double)rtm::acosf_rt(normal.y) / 3.1415);
+                }
             }
             int ci = f2i(ty * (float)fc.tex_h) * fc.tex_w + f2i(tx * (float)fc.tex_w);
             const int last = fc.tex_w * fc.tex_h - 1;
@@ -545,7 +603,9 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
             const float gx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hcx), first));
             const float gy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hcy), first));
             const float gz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hcz), first));
-            const bool inc = hit && ((rem >> lane) & 1ull) && (lane == first || (hcx == gx && hcy == gy && hcz == gz));
+            const int gk = __builtin_amdgcn_readlane(hkind, first);
+            const bool inc = hit && ((rem >> lane) & 1ull) &&
+                             (lane == first || (hkind == gk && hcx == gx && hcy == gy && hcz == gz));
             rem &= ~__ballot(inc);
             if (STATS == 1) st_clusters += 1;
             for (int li = 0; li < fc.n_lights; ++li) {
@@ -676,6 +736,22 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                             cur = nxt;
                             if (STATS == 1) { st_shadow += __popcll(__ballot(lit)); st_slots += 64; }
                             if (__all(shadowed)) break;
+                        }
+                    }
+                    // planes (kernel.cu:1511-1523) then cubes (:1524-1536), any-hit
+                    if ((fc.n_planes | fc.n_cubes) != 0 && !__all(shadowed)) {
+                        for (int i = 0; i < fc.n_planes; ++i) {
+                            float t;
+                            if (!shadowed && plane_intersect(fc.planes[i], start, new_dir, t)) shadowed = true;
+                            if (__all(shadowed)) break;
+                        }
+                        if (fc.n_cubes > 0 && !__all(shadowed)) {
+                            const V3 inv{1.f / new_dir.x, 1.f / new_dir.y, 1.f / new_dir.z};
+                            for (int i = 0; i < fc.n_cubes; ++i) {
+                                float t;
+                                if (!shadowed && cube_intersect(fc.cubes[i], start, inv, t)) shadowed = true;
+                                if (__all(shadowed)) break;
+                            }
                         }
                     }
                     if (!shadowed) unshadowed += 1;   // b += 0.1, kernel.cu:1537-1539

@@ -22,6 +22,26 @@ extern "C" void rt_sphere_init(rt_sphere *s, float x, float y, float z, float r)
     s->radius = r * r;   // kernel.cu:287 -- intersect() squares it once more (:334)
 }
 
+// plane(pos, normal), kernel.cu:364-367
+extern "C" void rt_plane_init(rt_plane *p, float px, float py, float pz, float nx, float ny, float nz)
+{
+    memset(p, 0, sizeof *p);
+    p->orgin.x = px; p->orgin.y = py; p->orgin.z = pz;
+    p->normal.x = nx; p->normal.y = ny; p->normal.z = nz;
+}
+
+// cube(c1, c2), kernel.cu:391-396: orgin = divide(add(c1, c2), 2)
+extern "C" void rt_cube_init(rt_cube *c, float ax, float ay, float az, float bx, float by, float bz)
+{
+    memset(c, 0, sizeof *c);
+    c->bounds[0].x = ax; c->bounds[0].y = ay; c->bounds[0].z = az;
+    c->bounds[1].x = bx; c->bounds[1].y = by; c->bounds[1].z = bz;
+    c->orgin.x = (ax + bx) / 2;
+    c->orgin.y = (ay + by) / 2;
+    c->orgin.z = (az + bz) / 2;
+    c->normals[0].x = 1; c->normals[1].y = 1; c->normals[2].z = 1;   // kernel.cu:507
+}
+
 // The reference fills the scene from un-seeded C rand() under MSVC, i.e. the
 // ucrt LCG from state 1: state = state*214013 + 2531011; return (state>>16)&0x7fff.
 struct MsvcRand {

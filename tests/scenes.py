@@ -61,3 +61,26 @@ GOLDEN_CASES = {
     "c3_3840x2160_rows300": (3840, 2160, 1024, 300, 302),
     "c5_128x72_n4096": (128, 72, 4096, 0, 72),
 }
+
+
+def mixed_scene(rt):
+    """Spheres + cubes + planes: 200 spheres of the rand()
+    replay, the reference's own plane (kernel.cu:1187) and a few boxes."""
+    import ctypes as C
+    lib = rt.load_library()
+    inp = Inputs(rt, 200)
+    planes = (rt.Plane * 2)()
+    lib.rt_plane_init(C.byref(planes[0]), 0.0, -4.0, 0.0, 0.0, 1.0, 0.0)
+    lib.rt_plane_init(C.byref(planes[1]), 0.0, 0.0, -3.0, 0.0, 0.25, 1.0)
+    boxes = [(1, 0, 1, 3, 2, 3), (6, 1, 2, 7.5, 2.5, 3.5), (4, 4, 4, 5, 6, 5), (8, -3, 8, 9.5, -1, 9.5), (2.5, 2, 8, 3.5, 3, 9)]
+    cubes = (rt.Cube * len(boxes))()
+    for i, b in enumerate(boxes):
+        lib.rt_cube_init(C.byref(cubes[i]), *[float(v) for v in b])
+    inp.planes, inp.n_planes, inp.cubes, inp.n_cubes = planes, 2, cubes, len(boxes)
+    return inp
+
+
+def mixed_oracle_render(inp, oracle, width, height, **kw):
+    return oracle.render(inp.spheres, inp.n, inp.tex, inp.sky, inp.sky_box, inp.lights, inp.n_lights, inp.cam,
+                         width, height, inp.aspect, cubes=inp.cubes, n_cubes=inp.n_cubes, planes=inp.planes,
+                         n_planes=inp.n_planes, nthreads=kw.get("nthreads", 8))

@@ -44,6 +44,7 @@ def test_struct_layouts(rt):
     assert C.sizeof(rt.Camera) == 36 and C.sizeof(rt.Light) == 28
     assert C.sizeof(rt.Sphere) == 32 and rt.Sphere.orgin.offset == 8 and rt.Sphere.radius.offset == 24
     assert C.sizeof(rt.Buffer) == 16 and C.sizeof(rt.Sprite) == 32 and C.sizeof(rt.Skybox) == 16
+    assert C.sizeof(rt.Plane) == 40 and rt.Plane.normal.offset == 24 and C.sizeof(rt.Cube) == 80 and rt.Cube.bounds.offset == 56
     assert C.sizeof(rt.Object) == 104
     assert rt.Object.d_spheres.offset == 24 and rt.Object.texture.offset == 72
 
@@ -73,10 +74,14 @@ def test_argument_validation_without_gpu_work(rt):
     obj = rt.Object()
     sky = rt.Skybox()
     lights = rt.default_lights()
-    # out-of-scope primitives are refused, not ignored
-    obj.cube_count = 1
+    # the out-of-scope primitive (triangle mesh) is refused, not ignored
+    obj.mesh1 = 0x1234
     rc = lib.rt_launch_raytrace(None, 64, 64, 1.0, C.byref(obj), lights, 3, rt.default_camera(), C.byref(sky), None)
     assert rc == 2 and b"outside" in lib.rt_last_error()
+    obj.mesh1 = None
+    obj.cube_count = 1                      # a count without a list is invalid
+    rc = lib.rt_launch_raytrace(None, 64, 64, 1.0, C.byref(obj), lights, 3, rt.default_camera(), C.byref(sky), None)
+    assert rc == 1
     obj.cube_count = 0
     rc = lib.rt_launch_raytrace(None, 64, 64, 1.0, C.byref(obj), lights, 3, rt.default_camera(), C.byref(sky), None)
     assert rc == 1        # skybox missing

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from scenes import GOLDEN_CASES, Inputs
+from scenes import GOLDEN_CASES, Inputs, mixed_oracle_render, mixed_scene
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -38,3 +38,11 @@ def test_spp4_golden(rt, oracle):
     assert np.array_equal(acc.view(np.uint32), g["acc"].view(np.uint32))
     assert np.array_equal(packed, g["packed"])
     assert (acc[..., 3] == 4).all()
+
+
+def test_mixed_primitives_golden(rt, oracle):
+    g = np.load(os.path.join(GOLD, "mixed_160x96.npz"))
+    rgba, packed, cnt = mixed_oracle_render(mixed_scene(rt), oracle, 160, 96)
+    assert np.array_equal(rgba[..., :3].view(np.uint32), g["rgb"].view(np.uint32))
+    assert np.array_equal(packed, g["packed"])
+    assert cnt["hit_pixels"] == int(g["counters"][2]) > 160 * 96 * 0.8      # the plane fills most of the lower image

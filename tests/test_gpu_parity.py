@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from scenes import GOLDEN_CASES, Inputs
+from scenes import GOLDEN_CASES, Inputs, mixed_scene
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -150,6 +150,18 @@ def test_frame_matches_golden(name, cull, rt, gpu):
     else:
         assert stats["primary_tests"] <= cnt[0]
         assert stats["unshadowed"] <= cnt[3]             # lights a surface faces away from are skipped
+
+
+@pytest.mark.parametrize("cull", [True, False])
+def test_mixed_primitives_match_golden(cull, rt, gpu):
+    g = np.load(os.path.join(GOLD, "mixed_160x96.npz"))
+    inp = mixed_scene(rt)
+    scene = inp.scene()
+    scene.set_planes(inp.planes, inp.n_planes)
+    scene.set_cubes(inp.cubes, inp.n_cubes)
+    rgba, packed, stats = _render(scene, 160, 96, cull=cull, want_stats=True)
+    assert np.array_equal(_bits(rgba[..., :3]), _bits(g["rgb"])) and np.array_equal(packed, g["packed"])
+    assert stats["hit_pixels"] == int(g["counters"][2])
 
 
 @pytest.mark.parametrize("tile", [8, 16, 32, 64])
@@ -311,10 +323,24 @@ def test_raytrace_launch_signature_on_managed_scene(rt, gpu):
     _, want2, _ = oracle_py.render(sph2, n, inp.tex, inp.sky, inp.sky_box, inp.lights, 3, inp.cam, w, h, inp.aspect,
                                    nthreads=8)
     assert np.array_equal(got2, want2) and not np.array_equal(got2, got)
-    # out-of-scope primitive -> refused
-    obj.contents.plane_count = 1
+    # planes and cubes ride along in the same object graph (kernel.cu:1213-1228)
+    pl = C.cast(lib.rt_managed_alloc(40), C.POINTER(rt.Plane))
+    lib.rt_plane_init(pl, 0.0, -4.0, 0.0, 0.0, 1.0, 0.0)          # the reference's plane, kernel.cu:1187
+    cu = C.cast(lib.rt_managed_alloc(80 * 2), C.POINTER(rt.Cube))
+    lib.rt_cube_init(C.byref(cu[0]), 1.0, 0.0, 1.0, 3.0, 2.0, 3.0)
+    lib.rt_cube_init(C.byref(cu[1]), 6.0, 1.0, 2.0, 7.5, 2.5, 3.5)
+    obj.contents.d_planes, obj.contents.plane_count = pl, 1
+    obj.contents.d_cubes, obj.contents.cube_count = cu, 2
+    assert lib.rt_launch_raytrace(pixels, w, h, inp.aspect, obj, inp.lights, 3, inp.cam, sky, None) == 0
+    torch.cuda.synchronize()
+    got3 = np.ctypeslib.as_array(C.cast(pixels, C.POINTER(C.c_uint32)), shape=(h, w)).copy()
+    _, want3, _ = oracle_py.render(sph2, n, inp.tex, inp.sky, inp.sky_box, inp.lights, 3, inp.cam, w, h, inp.aspect,
+                                   nthreads=8, cubes=cu, n_cubes=2, planes=pl, n_planes=1)
+    assert np.array_equal(got3, want3) and not np.array_equal(got3, got2)
+    # the one out-of-scope primitive (triangle mesh) -> refused
+    obj.contents.mesh1 = 0x10
     assert lib.rt_launch_raytrace(pixels, w, h, inp.aspect, obj, inp.lights, 3, inp.cam, sky, None) == 2
-    obj.contents.plane_count = 0
+    obj.contents.mesh1 = None
 
 
 def test_onstart_update_present_path(rt, gpu):

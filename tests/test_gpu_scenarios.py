@@ -17,13 +17,21 @@ def _bits(a):
 class Scn:
     """Free-form scene: explicit spheres (x,y,z,ctor_r), lights, camera, textures."""
 
-    def __init__(self, rt, spheres, lights=None, cam=None, tex=None, sky=None, sky_size=10000.0, aspect=None):
+    def __init__(self, rt, spheres, lights=None, cam=None, tex=None, sky=None, sky_size=10000.0, aspect=None,
+                 planes=(), cubes=()):
         self.rt = rt
         lib = rt.load_library()
         self.n = len(spheres)
         self.spheres = (rt.Sphere * max(self.n, 1))()
         for i, (x, y, z, r) in enumerate(spheres):
             lib.rt_sphere_init(C.byref(self.spheres[i]), float(x), float(y), float(z), float(r))
+        self.n_planes, self.n_cubes = len(planes), len(cubes)
+        self.planes = (rt.Plane * max(self.n_planes, 1))()
+        for i, v in enumerate(planes):
+            lib.rt_plane_init(C.byref(self.planes[i]), *[float(x) for x in v])
+        self.cubes = (rt.Cube * max(self.n_cubes, 1))()
+        for i, v in enumerate(cubes):
+            lib.rt_cube_init(C.byref(self.cubes[i]), *[float(x) for x in v])
         if lights is None:
             self.lights, self.n_lights = rt.default_lights(), 3
         else:
@@ -43,6 +51,10 @@ class Scn:
         s.set_texture(self.tex)
         s.set_sky(self.sky_box, self.sky)
         s.set_lights(self.lights, self.n_lights)
+        if getattr(self, "n_planes", 0):
+            s.set_planes(self.planes, self.n_planes)
+        if getattr(self, "n_cubes", 0):
+            s.set_cubes(self.cubes, self.n_cubes)
         return s
 
     def check(self, w, h, tiles=(8,), spp=1, nthreads=16):
@@ -55,7 +67,9 @@ class Scn:
             assert lib.rt_sample_offset(k, spp, C.byref(ox), C.byref(oy)) == 0
             rgba, packed, cnt = oracle_py.render(self.spheres, self.n, self.tex, self.sky, self.sky_box, self.lights,
                                                  self.n_lights, self.cam, w, h, self.aspect,
-                                                 off=(ox.value, oy.value), nthreads=nthreads)
+                                                 off=(ox.value, oy.value), nthreads=nthreads,
+                                                 cubes=getattr(self, "cubes", None), n_cubes=getattr(self, "n_cubes", 0),
+                                                 planes=getattr(self, "planes", None), n_planes=getattr(self, "n_planes", 0))
             acc = rgba if acc is None else (acc + rgba).astype(np.float32)
         sc = self.scene()
         for tile in tiles:
@@ -201,3 +215,54 @@ def test_texture_values_outside_unit_range(rt, gpu):
     tex[2][8, 2] = np.float32("nan")
     sph = [tuple(rng.uniform(0, 10, 3)) + (rng.uniform(0.4, 1.0),) for _ in range(60)]
     Scn(rt, sph, tex=tex).check(96, 64)
+
+
+# ---------------------------------------------------------------- cubes and planes
+def test_reference_plane_under_the_spheres(rt, gpu):
+    """The reference's own plane ({0,-4,0}, normal +y, kernel.cu:1187) below the
+    default sphere scene: plane pixels take texel (0.5,0.5) and are shadowed by spheres."""
+    from scenes import Inputs
+    inp = Inputs(rt, 256)
+    s = _as_scn(rt, inp)
+    lib = rt.load_library()
+    s.n_planes, s.planes = 1, (rt.Plane * 1)()
+    lib.rt_plane_init(C.byref(s.planes[0]), 0.0, -4.0, 0.0, 0.0, 1.0, 0.0)
+    s.n_cubes, s.cubes = 0, (rt.Cube * 1)()
+    cnt = s.check(160, 90, tiles=(8, 32))
+    assert cnt["hit_pixels"] > 9401          # more than the spheres alone (golden C2 count)
+
+
+def test_cubes_planes_and_spheres_mixed(rt, gpu):
+    rng = np.random.default_rng(21)
+    sph = [tuple(rng.uniform(0, 10, 3)) + (rng.uniform(0.3, 0.9),) for _ in range(120)]
+    cubes = []
+    for _ in range(12):
+        a = rng.uniform(0, 9, 3)
+        cubes.append(tuple(a) + tuple(a + rng.uniform(0.3, 1.5, 3)))
+    cubes.append((8, 0, 8, 6, 2, 6))                       # corners given in the "wrong" order
+    planes = [(0, -1, 0, 0, 1, 0), (0, 0, -2, 0.2, 0.1, 1.0), (12, 0, 0, -1, 0, 0)]   # one with a non-unit normal
+    Scn(rt, sph, planes=planes, cubes=cubes).check(128, 80, tiles=(8, 16))
+
+
+def test_only_cubes_and_planes_camera_inside_a_cube(rt, gpu):
+    # no spheres at all; the camera (4,3,~9) sits inside the first cube: negative tmin hit
+    cubes = [(3, 2, 8, 5, 4, 10), (0, 0, 0, 2, 2, 2), (6, 1, 1, 7, 5, 2)]
+    planes = [(0, -3, 0, 0, 1, 0)]
+    cnt = Scn(rt, [], planes=planes, cubes=cubes).check(96, 64)
+    assert cnt["hit_pixels"] == 96 * 64
+
+
+def test_axis_aligned_rays_hit_cube_slabs_exactly(rt, gpu):
+    # yaw 0 / pitch 0 and a centred pixel give direction components that are exactly 0
+    # for some lanes: 1/0 = inf and 0*inf = NaN flow through the min/max macros
+    cubes = [(3, 2, 12, 5, 4, 14), (4, 3, 15, 6, 5, 16)]
+    cam = _cam(rt, (4, 3, 2), 0.0, 0.0)
+    Scn(rt, [(4, 3, 20, 1.0)], cubes=cubes, cam=cam).check(64, 64, tiles=(8, 64))
+
+
+def test_too_many_planes_or_cubes_are_refused(rt, gpu):
+    s = rt.Scene()
+    with pytest.raises(rt.RtError):
+        s.set_planes((rt.Plane * 65)(), 65)
+    with pytest.raises(rt.RtError):
+        s.set_cubes((rt.Cube * 257)(), 257)

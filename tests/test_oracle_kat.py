@@ -196,3 +196,61 @@ def test_c1_plumbing_frame(oracle, rt, libm):
     lib = oracle.load()
     for (y, x) in ((0, 0), (128, 128), (255, 255), (200, 17)):
         assert packed[y, x] == lib.oracle_pack_color(*[float(v) for v in rgba[y, x, :3]])
+
+
+# ---------------------------------------------------------------- cube / plane
+def _ray(o, org, d):
+    return o.ORay(o.OVec3(*org), o.OVec3(*d))
+
+
+def test_plane_and_cube_layouts(oracle):
+    assert C.sizeof(oracle.OPlane) == 40 and oracle.OPlane.normal.offset == 24      # kernel.cu:1214: sizeof(float)*10
+    assert C.sizeof(oracle.OCube) == 80 and oracle.OCube.bounds.offset == 56
+
+
+def test_plane_intersect_kats(oracle):
+    lib = oracle.load()
+    p = oracle.OPlane()
+    lib.oracle_make_plane(C.byref(p), 0, -4, 0, 0, 1, 0)            # the reference's own plane, kernel.cu:1187
+    t = C.c_float(123.0)
+    # looking down: denom = -1 < 0, t = (-4)/(-1) = 4
+    assert lib.oracle_plane_intersect(C.byref(p), C.byref(_ray(oracle, (0, 0, 0), (0, -1, 0))), C.byref(t)) == 1 and t.value == 4.0
+    # looking up or parallel: denom >= 0 -> false and t is left untouched (kernel.cu:374-379)
+    t = C.c_float(123.0)
+    assert lib.oracle_plane_intersect(C.byref(p), C.byref(_ray(oracle, (0, 0, 0), (0, 1, 0))), C.byref(t)) == 0 and t.value == 123.0
+    assert lib.oracle_plane_intersect(C.byref(p), C.byref(_ray(oracle, (0, 0, 0), (1, 0, 0))), C.byref(t)) == 0
+    # below the plane looking down: t = 2/(-1) = -2 -> false, but t is written
+    assert lib.oracle_plane_intersect(C.byref(p), C.byref(_ray(oracle, (0, -6, 0), (0, -1, 0))), C.byref(t)) == 0 and t.value == -2.0
+    # the normal is used as given: a normal of length 2 halves nothing (t = dot(pl0,n)/dot(n,D) is scale free)
+    lib.oracle_make_plane(C.byref(p), 0, -4, 0, 0, 2, 0)
+    assert lib.oracle_plane_intersect(C.byref(p), C.byref(_ray(oracle, (0, 0, 0), (0, -1, 0))), C.byref(t)) == 1 and t.value == 4.0
+
+
+def test_cube_intersect_kats(oracle):
+    lib = oracle.load()
+    c = oracle.OCube()
+    lib.oracle_make_cube(C.byref(c), 1, 1, 1, 3, 3, 3)
+    assert (c.orgin.x, c.orgin.y, c.orgin.z) == (2, 2, 2)           # divide(add(c1,c2),2), kernel.cu:395
+    t = C.c_float()
+    # axis-aligned ray: 1/0 = inf on two axes, slabs give (-inf, +inf) there
+    assert lib.oracle_cube_intersect(C.byref(c), C.byref(_ray(oracle, (0, 2, 2), (1, 0, 0))), C.byref(t)) == 1 and t.value == 1.0
+    # origin inside: tmin = -1 < 0 < tmax -> TRUE with a negative t (like the sphere's negative root)
+    assert lib.oracle_cube_intersect(C.byref(c), C.byref(_ray(oracle, (2, 2, 2), (1, 0, 0))), C.byref(t)) == 1 and t.value == -1.0
+    # behind: tmax = -1 < 0 -> false, t = tmax
+    assert lib.oracle_cube_intersect(C.byref(c), C.byref(_ray(oracle, (4, 2, 2), (1, 0, 0))), C.byref(t)) == 0 and t.value == -1.0
+    # miss beside it: tmax < tmin -> false
+    assert lib.oracle_cube_intersect(C.byref(c), C.byref(_ray(oracle, (0, 5, 2), (1, 0, 0))), C.byref(t)) == 0
+    # diagonal through the corner region
+    d = 1 / math.sqrt(3)
+    assert lib.oracle_cube_intersect(C.byref(c), C.byref(_ray(oracle, (0, 0, 0), (d, d, d))), C.byref(t)) == 1
+    assert abs(t.value - math.sqrt(3)) < 1e-6
+    # swapped corners behave the same (min/max per slab)
+    lib.oracle_make_cube(C.byref(c), 3, 3, 3, 1, 1, 1)
+    assert lib.oracle_cube_intersect(C.byref(c), C.byref(_ray(oracle, (0, 2, 2), (1, 0, 0))), C.byref(t)) == 1 and t.value == 1.0
+    # on a slab boundary with a zero direction component: (bound - org) * inf = 0 * inf = NaN; the
+    # reference's max/min MACROS then pick their second operand (kernel.cu:16-26)
+    lib.oracle_make_cube(C.byref(c), 1, 1, 1, 3, 3, 3)
+    r = lib.oracle_cube_intersect(C.byref(c), C.byref(_ray(oracle, (0, 1, 2), (1, 0, 0))), C.byref(t))
+    t3, t4 = float("nan"), float("inf")        # (1-1)*inf, (3-1)*inf
+    mn = t3 if t3 < t4 else t4                 # MIN(t3,t4) -> t4 = inf
+    assert mn == float("inf") and r == 0       # tmin = inf > tmax -> false

@@ -17,7 +17,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 
 import oracle_py  # noqa: E402
 import rt_amd  # noqa: E402
-from scenes import GOLDEN_CASES, Inputs  # noqa: E402
+from scenes import GOLDEN_CASES, Inputs, mixed_oracle_render, mixed_scene  # noqa: E402
 
 
 def main():
@@ -36,6 +36,12 @@ def main():
     acc, packed = inp.oracle_render_spp(oracle_py, rt, 96, 54, 4)
     np.savez_compressed(os.path.join(out_dir, "spp4_96x54_n256.npz"), acc=acc, packed=packed)
     print("spp4_96x54_n256", acc.shape)
+    # spheres + cubes + planes
+    rgba, packed, cnt = mixed_oracle_render(mixed_scene(rt), oracle_py, 160, 96)
+    np.savez_compressed(os.path.join(out_dir, "mixed_160x96.npz"), rgb=rgba[..., :3].copy(), packed=packed,
+                        counters=np.array([cnt["primary_tests"], cnt["shadow_tests"], cnt["hit_pixels"],
+                                           cnt["unshadowed"]], dtype=np.uint64))
+    print("mixed_160x96", cnt)
 
 
 if __name__ == "__main__":
