@@ -25,7 +25,7 @@
 
 // launchers defined in rt_kernels.hip
 extern "C" hipError_t rt_dev_launch_trace(const RtFrameConsts *fc, const float4 *spheres, int tile_w,
-                                          int cull, int stats, hipStream_t stream);
+                                          int cull, int stats, int table_in_lds, hipStream_t stream);
 extern "C" hipError_t rt_dev_launch_dbg_math(int op, const float *a, const float *b, float *out, int n,
                                              hipStream_t stream);
 extern "C" hipError_t rt_dev_launch_dbg_intersect(const float4 *tab, const float *rays, int n, int *hit,
@@ -123,7 +123,18 @@ struct rt_scene {
     int n_planes = 0, n_cubes = 0;
 };
 
+// Largest table a workgroup can stage in LDS next to its lists, and the size up
+// to which staging is used by default (above it the kernel reads the table from
+// global memory and keeps only the survivor lists in LDS).
 static const int kMaxSpheresLds = (160 * 1024 - RT_WAVES_PER_WG * RT_LIST_CAP * 16) / 16;
+static const int kMaxSpheres = 1 << 22;
+static int table_in_lds_for(int n)
+{
+    const char *e = getenv("RT_TABLE_LDS");   // tuning/testing override: 0 or 1
+    if (e && *e == '0') return 0;
+    if (e && *e == '1') return n <= kMaxSpheresLds ? 1 : 0;
+    return n <= RT_TABLE_LDS_MAX ? 1 : 0;
+}
 
 extern "C" rt_scene *rt_scene_create(void) { return new rt_scene(); }
 
@@ -161,8 +172,8 @@ int rt_scene_set_spheres_async(rt_scene *s, const rt_sphere *host_spheres, int n
         rt_set_error("rt_scene_set_spheres: invalid argument");
         return RT_ERR_INVALID;
     }
-    if (n > kMaxSpheresLds) {
-        rt_set_error("rt_scene_set_spheres: %d spheres exceed the LDS-staged limit of %d", n, kMaxSpheresLds);
+    if (n > kMaxSpheres) {
+        rt_set_error("rt_scene_set_spheres: %d spheres exceed the limit of %d", n, kMaxSpheres);
         return RT_ERR_CAPACITY;
     }
     if (n > s->cap_spheres) {
@@ -491,7 +502,7 @@ extern "C" int rt_scene_render(rt_scene *s, const rt_frame_desc *fd, void *strea
     if (fc.local_rows == 0) return RT_OK;   // this rank owns no rows of the frame
     const int cull = (fd->opts.cull == 0) ? 0 : 1;
     const int stats = fd->opts.stats ? (fd->opts.profile ? 2 : 1) : 0;
-    RT_HIP(rt_dev_launch_trace(&fc, s->d_spheres, tile, cull, stats, (hipStream_t)stream));
+    RT_HIP(rt_dev_launch_trace(&fc, s->d_spheres, tile, cull, stats, table_in_lds_for(s->n_spheres), (hipStream_t)stream));
     return RT_OK;
 }
 

@@ -258,14 +258,37 @@ __device__ __forceinline__ bool beam_keeps(const Beam &b, float4 s)
     return (reach >= 0.f) && (d2 <= rad * rad * 1.0005f);
 }
 
-template <int STATS>
-__device__ __forceinline__ int build_list(const float4 *tab, int n, float4 *list, const Beam &b,
-                                          int lane, unsigned long long &n_cull)
+// The sphere table is either the workgroup's LDS copy (TABLDS, up to a few
+// thousand spheres) or read straight from global memory (any N; coalesced 16 B
+// per lane, L2-resident), in which case LDS only holds the survivor lists.
+template <bool TABLDS>
+__device__ __forceinline__ float4 table_at(const float4 *lds_tab, const float4 *__restrict__ gl_tab, int i)
+{
+    if constexpr (TABLDS) return lds_tab[i];
+    else return gl_tab[i];
+}
+// An entry of the list being walked: the wave's survivor list, or the whole table.
+template <bool TABLDS>
+__device__ __forceinline__ float4 entry_at(bool use_list, const float4 *list, const float4 *lds_tab,
+                                           const float4 *__restrict__ gl_tab, int e)
+{
+    if constexpr (TABLDS) {
+        const float4 *p = use_list ? list : lds_tab;
+        return p[e];
+    } else {
+        if (use_list) return list[e];
+        return gl_tab[e];
+    }
+}
+
+template <int STATS, bool TABLDS>
+__device__ __forceinline__ int build_list(const float4 *tab, const float4 *__restrict__ gtab, int n, float4 *list,
+                                          const Beam &b, int lane, unsigned long long &n_cull)
 {
     int count = 0;
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
-        const float4 s = tab[i < n ? i : n - 1];
+        const float4 s = table_at<TABLDS>(tab, gtab, i < n ? i : n - 1);
         const bool keep = (i < n) && beam_keeps(b, s);
         const unsigned long long m = __ballot(keep);
         const int pos = count + lane_prefix(m);
@@ -377,7 +400,7 @@ __device__ __forceinline__ void shadow_test(const RayK &sr, float4 s, bool &shad
 // ---------------------------------------------------------------------------
 // STATS: 0 = product kernel, 1 = work counters, 2 = per-phase cycle stamps
 // (s_memtime; a diagnostic build whose run time is never quoted).
-template <int TW, bool CULL, int STATS>
+template <int TW, bool CULL, int STATS, bool TABLDS>
 __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void rt_trace_tiles(const RtFrameConsts fc,
                                                                      const float4 *__restrict__ spheres)
 {
@@ -393,9 +416,11 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
 
     // ---- stage the sphere table into LDS (coalesced 16 B/lane) ----
     float4 *tab = lds;
-    for (int i = tid; i < n; i += 64 * RT_WAVES_PER_WG) tab[i] = spheres[i];
-    __syncthreads();
-    float4 *mylist = lds + n_pad + wave * RT_LIST_CAP;
+    if constexpr (TABLDS) {
+        for (int i = tid; i < n; i += 64 * RT_WAVES_PER_WG) tab[i] = spheres[i];
+        __syncthreads();
+    }
+    float4 *mylist = lds + (TABLDS ? n_pad : 0) + wave * RT_LIST_CAP;
 
     const int tile_x = (blockIdx.x * WGX + (wave % WGX)) * TW;
     // local row -> global row: a contiguous band, or row blocks dealt round-robin
@@ -451,7 +476,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
 
         phase(0);
         // ================= castRay, sphere branch =================
-        const float4 *plist = tab;
+        bool p_use_list = false;   // false: walk the whole table
         int pcount = n;
         if (CULL) {
             // cone around the tile's mean direction, apex at the (shared) origin
@@ -470,9 +495,9 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
             b.smin = 0.f;
             b.r0 = 1.0e-4f;
             if (ok) {
-                const int c = build_list<STATS>(tab, n, mylist, b, lane, st_cull);
+                const int c = build_list<STATS, TABLDS>(tab, spheres, n, mylist, b, lane, st_cull);
                 if (c <= RT_LIST_CAP) {
-                    plist = mylist;
+                    p_use_list = true;
                     pcount = c;
                 } else if (STATS == 1) {
                     st_overflow += 1;
@@ -484,10 +509,10 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
         phase(1);
         float nt = __builtin_inff();
         float hcx = 0.f, hcy = 0.f, hcz = 0.f;   // centre of the closest sphere
-        float4 pcur = pcount > 0 ? plist[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 pcur = pcount > 0 ? entry_at<TABLDS>(p_use_list, mylist, tab, spheres, 0) : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int e = 0; e < pcount; ++e) {
             const float4 s = pcur;
-            pcur = plist[e + 1 < pcount ? e + 1 : e];   // keep one entry in flight
+            pcur = entry_at<TABLDS>(p_use_list, mylist, tab, spheres, e + 1 < pcount ? e + 1 : e);   // one entry in flight
             const Quad q = quadratic(pr, s);
             bool need = (q.disc >= 0.f);
             if (!fc.force_slow) need = need && !(q.h > 0.f && q.disc < q.BB * RT_BEHIND_FACTOR);
@@ -635,7 +660,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                 }
 
                 // ---------- conservative beam for this light's 10 x 64 rays ----------
-                const float4 *slist = tab;
+                bool s_use_list = false;
                 int scount = n;
                 if (CULL) {
                     bool ok = true;
@@ -700,9 +725,9 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                     phase(4);
                     if (fc.ablate & 4) { ok = false; scount = 0; }
                     if (ok) {
-                        const int c = build_list<STATS>(tab, n, mylist, b, lane, st_cull);
+                        const int c = build_list<STATS, TABLDS>(tab, spheres, n, mylist, b, lane, st_cull);
                         if (c <= RT_LIST_CAP) {
-                            slist = mylist;
+                            s_use_list = true;
                             scount = c;
                         } else if (STATS == 1) {
                             st_overflow += 1;
@@ -729,9 +754,10 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                     bool shadowed = !lit;   // lanes outside the group (or unlit) are simply done
                     const int scount_j = (fc.ablate & 1) ? 0 : scount;
                     if (scount_j > 0) {
-                        float4 cur = slist[0];
+                        float4 cur = entry_at<TABLDS>(s_use_list, mylist, tab, spheres, 0);
                         for (int e = 0; e < scount_j; ++e) {
-                            const float4 nxt = slist[e + 1 < scount_j ? e + 1 : e];   // keep one entry in flight
+                            const float4 nxt = entry_at<TABLDS>(s_use_list, mylist, tab, spheres,
+                                                                e + 1 < scount_j ? e + 1 : e);   // one entry in flight
                             shadow_test(sr, cur, shadowed, fc.force_slow != 0);
                             cur = nxt;
                             if (STATS == 1) { st_shadow += __popcll(__ballot(lit)); st_slots += 64; }
@@ -909,7 +935,7 @@ extern "C" hipError_t rt_dev_prepare(void)
     hipError_t e = hipSuccess;
 #define RT_ATTR(TW, C, S)                                                                          \
     if (e == hipSuccess)                                                                           \
-        e = hipFuncSetAttribute((const void *)rt_trace_tiles<TW, C, S>,                           \
+        e = hipFuncSetAttribute((const void *)rt_trace_tiles<TW, C, S, true>,                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
 #define RT_ATTR_TW(TW) RT_ATTR(TW, true, 0); RT_ATTR(TW, false, 0); RT_ATTR(TW, true, 1); RT_ATTR(TW, false, 1); RT_ATTR(TW, true, 2); RT_ATTR(TW, false, 2)
     RT_ATTR_TW(8);
@@ -923,10 +949,10 @@ extern "C" hipError_t rt_dev_prepare(void)
 }
 
 extern "C" hipError_t rt_dev_launch_trace(const RtFrameConsts *fc, const float4 *spheres, int tile_w,
-                                          int cull, int stats, hipStream_t stream)
+                                          int cull, int stats, int table_in_lds, hipStream_t stream)
 {
     const int n_pad = (fc->n_spheres + 63) & ~63;
-    const size_t lds_bytes = (size_t)(n_pad + RT_WAVES_PER_WG * RT_LIST_CAP) * sizeof(float4);
+    const size_t lds_bytes = (size_t)((table_in_lds ? n_pad : 0) + RT_WAVES_PER_WG * RT_LIST_CAP) * sizeof(float4);
     const int band_h = fc->local_rows;
     const int th = 64 / tile_w;
     const int wgx = (tile_w <= 16) ? 2 : 1;
@@ -939,7 +965,12 @@ extern "C" hipError_t rt_dev_launch_trace(const RtFrameConsts *fc, const float4 
     }
 
 #define RT_LAUNCH(TW, C, S)                                                                        \
-    hipLaunchKernelGGL((rt_trace_tiles<TW, C, S>), grid, block, lds_bytes, stream, *fc, spheres)
+    do {                                                                                           \
+        if (table_in_lds)                                                                          \
+            hipLaunchKernelGGL((rt_trace_tiles<TW, C, S, true>), grid, block, lds_bytes, stream, *fc, spheres);  \
+        else                                                                                       \
+            hipLaunchKernelGGL((rt_trace_tiles<TW, C, S, false>), grid, block, lds_bytes, stream, *fc, spheres); \
+    } while (0)
 #define RT_LAUNCH_TW(TW)                                                                           \
     do {                                                                                           \
         if (stats == 2) { if (cull) RT_LAUNCH(TW, true, 2); else RT_LAUNCH(TW, false, 2); }        \

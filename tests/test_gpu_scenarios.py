@@ -163,24 +163,45 @@ def test_random_seeds_and_counts(rt, gpu, n, seed):
     Scn.check(_as_scn(rt, Inputs(rt, n, seed)), 80, 56)
 
 
-def test_capacity_limits(rt, gpu):
-    from scenes import Inputs
-    lib = rt.load_library()
-    # just under the LDS-staged limit still renders (and matches brute force on a tiny frame)
-    n = 9000
-    inp = Inputs(rt, n, 12)
-    sc = inp.scene()
-    a = sc.render(24, 16, cull=True)
-    b = sc.render(24, 16, cull=False)
+def test_table_in_global_memory_matches_lds_staging(rt, gpu, monkeypatch):
+    """Above RT_TABLE_LDS_MAX spheres the kernel reads the table from global
+    memory instead of staging it in LDS; forcing that mode on small scenes must
+    not change a bit."""
     import torch
-    torch.cuda.synchronize()
-    assert torch.equal(a["rgba"], b["rgba"]) and torch.equal(a["packed"], b["packed"])
+    from scenes import Inputs
+    for n in (100, 1024):
+        sc = Inputs(rt, n, 3).scene()
+        monkeypatch.setenv("RT_TABLE_LDS", "1")
+        a = sc.render(160, 90)
+        monkeypatch.setenv("RT_TABLE_LDS", "0")
+        b = sc.render(160, 90)
+        c = sc.render(160, 90, cull=False)
+        torch.cuda.synchronize()
+        assert torch.equal(a["rgba"], b["rgba"]) and torch.equal(a["packed"], b["packed"])
+        assert torch.equal(a["rgba"], c["rgba"]) and torch.equal(a["packed"], c["packed"])
+    monkeypatch.delenv("RT_TABLE_LDS")
+
+
+def test_large_sphere_counts(rt, gpu):
+    """Maximum sizes: 9000 spheres still fit the LDS-staged kernel when forced,
+    20000 use the global-memory table; both equal the brute-force loops. The
+    oracle agrees on a tiny frame."""
+    import torch
+    from scenes import Inputs
+    for n in (9000, 20000):
+        inp = Inputs(rt, n, 12)
+        sc = inp.scene()
+        a = sc.render(24, 16, cull=True)
+        b = sc.render(24, 16, cull=False)
+        torch.cuda.synchronize()
+        assert torch.equal(a["rgba"], b["rgba"]) and torch.equal(a["packed"], b["packed"])
+    Scn.check(_as_scn(rt, Inputs(rt, 20000, 12)), 16, 8)
     s = rt.Scene()
-    big = rt.generate_spheres(20000, 1)
+    n = (1 << 22) + 1
+    big = rt.generate_spheres(n, 1)
     with pytest.raises(rt.RtError) as e:
-        s.set_spheres(big, 20000)
+        s.set_spheres(big, n)
     assert "exceed" in str(e.value)
-    assert lib.rt_last_error()
 
 
 @pytest.mark.parametrize("spp", [2, 3, 16])
