@@ -74,6 +74,23 @@ out["C5_7680x4320_n4096_rank3of8"] = {"ms": ms, "rows": rows, "Mrays_per_s_this_
 ms, _ = time_render(s4096, 7680, 4320, iters=3)
 out["C5_7680x4320_n4096_whole_frame_on_1_gpu"] = {"ms": ms, "Mrays_per_s": 7680 * 4320 / ms / 1e3, "fps": 1e3 / ms}
 
+# C5 with the extent scaled so that the sphere density matches the 1024-sphere case
+# (at N=4096 the generator encloses the camera in a sphere)
+scale = (4096 / 1024) ** (1.0 / 3.0)
+sph = rt.generate_spheres(4096, 1)
+import numpy as np
+for i in range(4096):
+    sph[i].orgin.x = float(np.float32(sph[i].orgin.x) * np.float32(scale))
+    sph[i].orgin.y = float(np.float32(sph[i].orgin.y) * np.float32(scale))
+    sph[i].orgin.z = float(np.float32(sph[i].orgin.z) * np.float32(scale))
+s4096s = rt.Scene.default(8)
+s4096s.set_spheres(sph, 4096)
+ms, _ = time_render(s4096s, 7680, 4320, iters=3)
+st = s4096s.render(960, 540, want_stats=True)["stats"]
+out["C5_scaled_extent_whole_frame_on_1_gpu"] = {"ms": ms, "Mrays_per_s": 7680 * 4320 / ms / 1e3, "fps": 1e3 / ms,
+                                                "hit_fraction_at_960x540": st["hit_pixels"] / (960 * 540),
+                                                "note": "sphere centres scaled by 4^(1/3): same density as C3"}
+
 # update(): kernel + D2H into the offscreen window (what the reference's boundary requires)
 lib.rt_config_set_sphere_count(1024)
 lib.rt_on_start()
