@@ -109,6 +109,8 @@ struct rt_scene {
     int n_spheres = 0, cap_spheres = 0;
     float4 *h_stage = nullptr;   // pinned staging for asynchronous re-uploads
     int cap_stage = 0;
+    hipEvent_t stage_done = nullptr;   // the last upload out of h_stage
+    bool stage_busy = false;
     float *d_tex[3] = {nullptr, nullptr, nullptr};
     int tex_w = 0, tex_h = 0;
     float *d_sky[3] = {nullptr, nullptr, nullptr};
@@ -151,6 +153,7 @@ extern "C" void rt_scene_destroy(rt_scene *s)
     if (!s) return;
     if (s->d_spheres) (void)hipFree(s->d_spheres);
     if (s->h_stage) (void)hipHostFree(s->h_stage);
+    if (s->stage_done) (void)hipEventDestroy(s->stage_done);
     free_planes(s->d_tex);
     free_planes(s->d_sky);
     if (s->d_planes) (void)hipFree(s->d_planes);
@@ -191,8 +194,13 @@ int rt_scene_set_spheres_async(rt_scene *s, const rt_sphere *host_spheres, int n
         s->cap_stage = n;
     }
     if (n > 0) {
+        // the staging buffer is reused every frame: wait for the previous upload to have left it
+        if (!s->stage_done) RT_HIP(hipEventCreateWithFlags(&s->stage_done, hipEventDisableTiming));
+        if (s->stage_busy) RT_HIP(hipEventSynchronize(s->stage_done));
         pack_spheres(host_spheres, n, s->h_stage);
         RT_HIP(hipMemcpyAsync(s->d_spheres, s->h_stage, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, stream));
+        RT_HIP(hipEventRecord(s->stage_done, stream));
+        s->stage_busy = true;
     }
     s->n_spheres = n;
     return RT_OK;

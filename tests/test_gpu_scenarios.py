@@ -287,3 +287,31 @@ def test_too_many_planes_or_cubes_are_refused(rt, gpu):
         s.set_planes((rt.Plane * 65)(), 65)
     with pytest.raises(rt.RtError):
         s.set_cubes((rt.Cube * 257)(), 257)
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_fuzz_random_scenes(rt, gpu, seed):
+    """Random scenes (sphere count/size/placement, lights anywhere including inside
+    the scene, camera pose, texture sizes, optional cubes/planes): culled kernel ==
+    brute-force kernel == oracle, bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(0, 300))
+    ext = float(rng.choice([3.0, 10.0, 40.0]))
+    sph = [tuple(rng.uniform(-ext * 0.2, ext, 3)) + (float(rng.choice([rng.uniform(0, 1), rng.uniform(1, 1.8), 0.05])),)
+           for _ in range(n)]
+    lights = []
+    for _ in range(int(rng.integers(0, 5))):
+        pos = rng.uniform(-30, 30, 3) if rng.random() < 0.7 else rng.uniform(0, ext, 3)
+        lights.append((tuple(pos), float(rng.uniform(0.5, 25)), *[float(v) for v in rng.uniform(0, 1.5, 3)]))
+    cam = _cam(rt, tuple(rng.uniform(-5, ext + 5, 3)), float(rng.uniform(0, 360)), float(rng.uniform(-60, 60)))
+    th, tw = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+    tex = [rng.integers(0, 256, (th, tw)).astype(np.float32) / np.float32(255) for _ in range(3)]
+    planes, cubes = [], []
+    if rng.random() < 0.4:
+        for _ in range(int(rng.integers(1, 3))):
+            nrm = rng.normal(size=3)
+            planes.append(tuple(rng.uniform(-5, ext, 3)) + tuple(nrm))
+        for _ in range(int(rng.integers(0, 6))):
+            a = rng.uniform(0, ext, 3)
+            cubes.append(tuple(a) + tuple(a + rng.uniform(0.1, 2.0, 3)))
+    Scn(rt, sph, lights=lights, cam=cam, tex=tex, planes=planes, cubes=cubes).check(64, 48, tiles=(8,))
