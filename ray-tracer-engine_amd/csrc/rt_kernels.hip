@@ -236,6 +236,7 @@ struct Beam {        // all members wave-uniform
     float ax, ay, az;   // a point on the axis
     float ux, uy, uz;   // unit axis
     float smin;         // rays start at axial coordinate >= smin
+    float smax;         // ... and <= smax (used only by the full-occluder test)
     float r0;           // ... within r0 of the axis
     float k;            // and spread with slope k = tan(theta)
 };
@@ -281,21 +282,45 @@ __device__ __forceinline__ float4 entry_at(bool use_list, const float4 *list, co
     }
 }
 
+// Sphere s certainly occludes EVERY ray of the beam: it lies entirely ahead of all
+// ray origins, and the beam's cross-section at the centre's axial coordinate --
+// radius r0 + k*(sa - smin) around the axis, both already padded -- sits inside
+// the sphere shrunk by the same rounding allowance the cull test adds. Each ray
+// then passes within that shrunken radius of the centre in its forward direction,
+// so the exact float test has disc > 0 and h far below -h_sure: it returns true.
+__device__ __forceinline__ bool beam_blocked_by(const Beam &b, float4 s)
+{
+    const float vx = s.x - b.ax, vy = s.y - b.ay, vz = s.z - b.az;
+    const float vv = __builtin_fmaf(vx, vx, __builtin_fmaf(vy, vy, vz * vz));
+    const float sa = __builtin_fmaf(vx, b.ux, __builtin_fmaf(vy, b.uy, vz * b.uz));
+    const float d2 = __builtin_fmaxf(__builtin_fmaf(-sa, sa, vv), 0.f);
+    const float r2b = s.w - __builtin_fmaf(4.0e-5f, vv, 1.0e-3f);        // shrunken radius^2
+    const float rr = __builtin_amdgcn_sqrtf(s.w);
+    const bool ahead = (sa - b.smax) >= __builtin_fmaf(rr, 1.001f, 0.01f);
+    const float rho = __builtin_fmaf(b.k, sa - b.smin, b.r0);
+    const float lhs = __builtin_fmaf(__builtin_amdgcn_sqrtf(d2) + rho, 1.001f, 1.0e-4f);
+    return ahead && (r2b > 0.f) && (lhs * lhs <= r2b);
+}
+
 template <int STATS, bool TABLDS>
 __device__ __forceinline__ int build_list(const float4 *tab, const float4 *__restrict__ gtab, int n, float4 *list,
-                                          const Beam &b, int lane, unsigned long long &n_cull)
+                                          const Beam &b, int lane, unsigned long long &n_cull,
+                                          bool *blocked = nullptr)
 {
     int count = 0;
+    bool blk = false;
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
         const float4 s = table_at<TABLDS>(tab, gtab, i < n ? i : n - 1);
         const bool keep = (i < n) && beam_keeps(b, s);
+        if (blocked) blk = blk || (keep && beam_blocked_by(b, s));
         const unsigned long long m = __ballot(keep);
         const int pos = count + lane_prefix(m);
         if (keep && pos < RT_LIST_CAP) list[pos] = s;
         count += __popcll(m);
         if (STATS == 1) n_cull += 64;
     }
+    if (blocked) *blocked = __any(blk);
     wave_lds_sync();
     return count;
 }
@@ -493,6 +518,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
             b.k = sn * __builtin_amdgcn_rsqf(1.f - sn * sn);
             b.ax = O.x; b.ay = O.y; b.az = O.z;
             b.smin = 0.f;
+            b.smax = 0.f;
             b.r0 = 1.0e-4f;
             if (ok) {
                 const int c = build_list<STATS, TABLDS>(tab, spheres, n, mylist, b, lane, st_cull);
@@ -651,10 +677,12 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                 // the light is skipped. (Not applied in the brute-force build, which
                 // runs the reference's loops as written and is what tests compare with.)
                 bool lit = inc;
+                bool zero_ok = false;   // brightness 0 adds exactly nothing for this lane
                 if (CULL && !fc.force_slow) {
                     const float a0 = dot3(normal, toL);
                     const float fin = (L.r * tr) * (L.g * tg) * (L.b * tb);   // finite iff all six are
-                    const bool away = (a0 < -1.0e-4f) && (__builtin_fabsf(fin) < __builtin_inff());
+                    zero_ok = (__builtin_fabsf(fin) < __builtin_inff()) && (__builtin_fabsf(a0) < 1.0e30f);
+                    const bool away = (a0 < -1.0e-4f) && zero_ok;
                     lit = inc && !away;
                     if (!__any(lit)) continue;
                 }
@@ -719,13 +747,26 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                     const float perp2 = __builtin_fmaxf(ox * ox + oy * oy + oz * oz - so * so, 0.f);
                     const float r2 = uniform(wave_max(lit ? perp2 : 0.f));
                     const float smin = uniform(wave_min(lit ? so : 3.0e38f));
+                    const float smax = uniform(wave_max(lit ? so : -3.0e38f));
                     ok = ok && (r2 < 1.0e30f) && (smin > -1.0e30f);
                     b.r0 = __builtin_amdgcn_sqrtf(r2) * 1.001f + 1.0e-3f;
                     b.smin = smin - 1.0e-3f - 1.0e-4f * __builtin_fabsf(smin);
+                    b.smax = smax + 1.0e-3f + 1.0e-4f * __builtin_fabsf(smax);
                     phase(4);
                     if (fc.ablate & 4) { ok = false; scount = 0; }
                     if (ok) {
-                        const int c = build_list<STATS, TABLDS>(tab, spheres, n, mylist, b, lane, st_cull);
+                        // One sphere in front of the whole beam shadows all 10 samples of
+                        // every lit lane: unshadowed = 0, b = 0, and the light adds exactly
+                        // nothing -- the sample construction and the tests are skipped.
+                        bool blocked = false;
+                        const bool may_skip = !fc.force_slow && !(fc.ablate & 64) && __all(!lit || zero_ok);
+                        const int c = build_list<STATS, TABLDS>(tab, spheres, n, mylist, b, lane, st_cull,
+                                                                may_skip ? &blocked : nullptr);
+                        if (blocked) {
+                            if (STATS == 1) hist[7] += 1;
+                            wave_lds_sync();
+                            continue;
+                        }
                         if (c <= RT_LIST_CAP) {
                             s_use_list = true;
                             scount = c;
