@@ -302,10 +302,11 @@ __device__ __forceinline__ bool beam_blocked_by(const Beam &b, float4 s)
     return ahead && (r2b > 0.f) && (lhs * lhs <= r2b);
 }
 
-template <int STATS, bool TABLDS>
+// Returns the survivor count; with OCCL bit 30 flags "one sphere occludes the
+// whole beam" (count | 0x40000000).
+template <int STATS, bool TABLDS, bool OCCL = false>
 __device__ __forceinline__ int build_list(const float4 *tab, const float4 *__restrict__ gtab, int n, float4 *list,
-                                          const Beam &b, int lane, unsigned long long &n_cull,
-                                          bool *blocked = nullptr)
+                                          const Beam &b, int lane, unsigned long long &n_cull)
 {
     int count = 0;
     bool blk = false;
@@ -313,15 +314,15 @@ __device__ __forceinline__ int build_list(const float4 *tab, const float4 *__res
         const int i = base + lane;
         const float4 s = table_at<TABLDS>(tab, gtab, i < n ? i : n - 1);
         const bool keep = (i < n) && beam_keeps(b, s);
-        if (blocked) blk = blk || (keep && beam_blocked_by(b, s));
+        if (OCCL) blk = blk || (keep && beam_blocked_by(b, s));
         const unsigned long long m = __ballot(keep);
         const int pos = count + lane_prefix(m);
         if (keep && pos < RT_LIST_CAP) list[pos] = s;
         count += __popcll(m);
         if (STATS == 1) n_cull += 64;
     }
-    if (blocked) *blocked = __any(blk);
     wave_lds_sync();
+    if (OCCL && __any(blk)) count |= 0x40000000;
     return count;
 }
 
@@ -456,6 +457,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
     const int py = (fc.il_count > 1) ? ((ly / fc.il_rows) * fc.il_count + fc.il_index) * fc.il_rows + (ly % fc.il_rows)
                                      : fc.y0 + ly;
     const bool valid = (px < fc.width) && (ly < fc.local_rows) && (py < fc.y1);
+    const unsigned out_idx = (unsigned)ly * (unsigned)fc.width + (unsigned)px;   // band-local pixel index
     if (!__any(valid)) return;   // wave-uniform; after the only workgroup barrier
 
     unsigned long long st_primary = 0, st_shadow = 0, st_cull = 0, st_slots = 0, st_entries = 0,
@@ -648,16 +650,26 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
             // the closest sphere (3.5 % of the 8x8 tiles at 4K see more than one):
             // each group's origins lie on one small patch, its beam is thin, its
             // list short -- and no wave runs orders of magnitude longer than the rest.
-            unsigned long long rem = __ballot(hit);
-            while (rem) {
-            const int first = __builtin_ctzll(rem);
-            const float gx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hcx), first));
-            const float gy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hcy), first));
-            const float gz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hcz), first));
-            const int gk = __builtin_amdgcn_readlane(hkind, first);
-            const bool inc = hit && ((rem >> lane) & 1ull) &&
-                             (lane == first || (hkind == gk && hcx == gx && hcy == gy && hcz == gz));
-            rem &= ~__ballot(inc);
+            // group ids first (the sphere centres / kinds they are derived from are
+            // not needed afterwards, which frees four registers for the light loop)
+            int gid = -1, n_groups = 0;
+            {
+                unsigned long long rem = __ballot(hit);
+                while (rem) {
+                    const int first = __builtin_ctzll(rem);
+                    const float gx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hcx), first));
+                    const float gy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hcy), first));
+                    const float gz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hcz), first));
+                    const int gk = __builtin_amdgcn_readlane(hkind, first);
+                    const bool in = hit && ((rem >> lane) & 1ull) &&
+                                    (lane == first || (hkind == gk && hcx == gx && hcy == gy && hcz == gz));
+                    if (in) gid = n_groups;
+                    rem &= ~__ballot(in);
+                    ++n_groups;
+                }
+            }
+            for (int g = 0; g < n_groups; ++g) {
+            const bool inc = hit && (gid == g);
             if (STATS == 1) st_clusters += 1;
             for (int li = 0; li < fc.n_lights; ++li) {
                 const RtLightDev L = fc.lights[li];
@@ -758,11 +770,10 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                         // One sphere in front of the whole beam shadows all 10 samples of
                         // every lit lane: unshadowed = 0, b = 0, and the light adds exactly
                         // nothing -- the sample construction and the tests are skipped.
-                        bool blocked = false;
                         const bool may_skip = !fc.force_slow && !(fc.ablate & 64) && __all(!lit || zero_ok);
-                        const int c = build_list<STATS, TABLDS>(tab, spheres, n, mylist, b, lane, st_cull,
-                                                                may_skip ? &blocked : nullptr);
-                        if (blocked) {
+                        const int cb = build_list<STATS, TABLDS, true>(tab, spheres, n, mylist, b, lane, st_cull);
+                        const int c = cb & 0x3fffffff;
+                        if (may_skip && (cb & 0x40000000)) {
                             if (STATS == 1) hist[7] += 1;
                             wave_lds_sync();
                             continue;
@@ -848,7 +859,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
 
     // ================= write-back =================
     if (valid) {
-        const size_t o = (size_t)ly * (size_t)fc.width + (size_t)px;
+        const size_t o = out_idx;
         float w = (float)fc.spp;
         if (fc.rgba) {
             float4 *dst = reinterpret_cast<float4 *>(fc.rgba) + o;
