@@ -346,6 +346,23 @@ struct ShadowChain {
         m00 = m01 = m02 = m10 = m11 = m12 = m20 = m21 = m22 = 0.f;
     }
 
+    // Only the evolution of toL over the ten iterations (two in-place
+    // normalisations each, kernel.cu:1465-1466), for callers that need the final
+    // toL of kernel.cu:1541 but none of the sample directions.
+    __device__ __forceinline__ void settle()
+    {
+#pragma unroll 1
+        for (int j = 0; j < RT_SHADOW_SAMPLES; ++j) {
+            if (__all(stable)) break;
+            if (!stable) {
+                const V3 tin = toL;
+                normalise_inplace(toL);
+                normalise_inplace(toL);
+                stable = (toL.x == tin.x) && (toL.y == tin.y) && (toL.z == tin.z);
+            }
+        }
+    }
+
     // Direction of sample j. Everything up to the rotation matrix depends on j
     // only through toL, which normalise() keeps re-normalising in place
     // (kernel.cu:1465-1466). Once two more normalisations leave toL
@@ -702,6 +719,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                 // ---------- conservative beam for this light's 10 x 64 rays ----------
                 bool s_use_list = false;
                 int scount = n;
+                float beam_k = 0.f;   // slope of the light's beam (valid when s_use_list)
                 if (CULL) {
                     bool ok = true;
                     Beam b;
@@ -781,12 +799,13 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                         if (c <= RT_LIST_CAP) {
                             s_use_list = true;
                             scount = c;
+                            beam_k = b.k;
                         } else if (STATS == 1) {
                             st_overflow += 1;
                         }
                         if (STATS == 1) st_entries += (unsigned long long)(c <= RT_LIST_CAP ? c : n);
                         if (STATS == 1) {
-                            const int bin = c <= 8 ? 0 : c <= 16 ? 1 : c <= 32 ? 2 : c <= 64 ? 3 : c <= 128 ? 4 : c <= RT_LIST_CAP ? 5 : 6;
+                            const int bin = c <= 1 ? 0 : c <= 2 ? 1 : c <= 4 ? 2 : c <= 8 ? 3 : c <= 16 ? 4 : c <= RT_LIST_CAP ? 5 : 6;
                             hist[bin] += 1;
                         }
                     }
@@ -797,8 +816,35 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                 ShadowChain chain;
                 chain.begin(lpos, start);
                 int unshadowed = 0;
+                // A short list whose every sphere lies behind every ray of the beam (for
+                // each lit lane: start outside the sphere by more than the `behind`
+                // shortcut needs, C > 2e-5*|oc|^2, and the whole cone of directions on the
+                // far side, cos(u,oc) > sin(u,oc)*tan(theta) + 0.02) leaves all ten samples
+                // unshadowed without constructing one of them: only toL's evolution is
+                // needed for kernel.cu:1541. Typically the list is just the sphere the
+                // tile itself lies on.
+                bool all_clear = false;
+                if (CULL && s_use_list && scount <= 4 && !fc.force_slow && !(fc.ablate & 128) &&
+                    (fc.n_planes | fc.n_cubes) == 0) {
+                    bool clear = true;
+                    for (int e = 0; e < scount; ++e) {
+                        const float4 sp = mylist[e];
+                        const float ocx = start.x - sp.x, ocy = start.y - sp.y, ocz = start.z - sp.z;
+                        const float q = ocx * ocx + ocy * ocy + ocz * ocz;
+                        const float C = q - sp.w;
+                        const float cu = (ocx * L.ux + ocy * L.uy + ocz * L.uz) * __builtin_amdgcn_rsqf(q);
+                        const float su = __builtin_amdgcn_sqrtf(__builtin_fmaxf(1.f - cu * cu, 0.f));
+                        clear = clear && (C > 2.0e-5f * q) && (cu > su * beam_k + 0.02f);
+                    }
+                    all_clear = __all(!lit || clear);
+                }
+                if (all_clear) {
+                    chain.settle();
+                    unshadowed = RT_SHADOW_SAMPLES;
+                    if (STATS == 1) hist[6] += 1;
+                }
 #pragma unroll 1
-                for (int j = 0; j < RT_SHADOW_SAMPLES; ++j) {
+                for (int j = 0; j < (all_clear ? 0 : RT_SHADOW_SAMPLES); ++j) {
                     const V3 new_dir = (fc.ablate & 2) ? chain.toL : chain.direction(fc, L, start, j);
                     const RayK sr = make_ray(start, new_dir);
                     phase(6);

@@ -26,6 +26,6 @@ print(json.dumps({"waves": waves, "cycles_per_wave": tot / waves,
                   "cycles_per_wave_by_phase": {k: round(v / waves, 1) for k, v in cyc.items()}}, indent=1))
 cnt = scene.render(a.width, a.height, want_stats=True, cull=not a.no_cull, tile=a.tile)["stats"]
 print(json.dumps({k: v for k, v in cnt.items() if not k.startswith("cyc_")}))
-names = ["<=8", "<=16", "<=32", "<=64", "<=128", "<=cap", "overflow", "full_occluder_skips"]
+names = ["<=1", "<=2", "<=4", "<=8", "<=16", "<=cap", "all_clear_skips", "full_occluder_skips"]
 print("shadow list length histogram:", dict(zip(names, [cnt[k] for k in list(cnt)[8:16]])))
 print("mean distinct hit spheres per hit wave:", cnt["clusters"] / max(1, waves))
