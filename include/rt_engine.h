@@ -86,6 +86,35 @@ typedef struct rt_cube {                                     /* cube : shape, ke
     rt_vec3 bounds[2];       /* the two corners of the slab test (kernel.cu:457-485)  */
 } rt_cube;                                                   /* 80 bytes */
 
+typedef struct rt_vec2 { float u, v; } rt_vec2;              /* vec2d, kernel.cu:32-34 */
+
+typedef struct rt_triangle {                                 /* triangle, kernel.cu:206-212 */
+    rt_vec3 points[3];
+    rt_vec3 normal;          /* face normal                                           */
+    rt_vec3 vecNormal[3];    /* vertex normals (used when mesh.has_normals)           */
+    rt_vec2 vt[3];           /* texture coordinates                                   */
+} rt_triangle;                                               /* 108 bytes (kernel.cu:1018-1020) */
+
+typedef struct rt_bvhbox {                                   /* Bvhbox, kernel.cu:512-543 */
+    rt_cube *bvhbox;         /* bounds of this leaf (read by the shadow path, :1479)  */
+    rt_cube *d_bvhbox;       /* same cube (read by castRay, :1297)                    */
+    int *indexes;
+    int *d_indexes;          /* triangle indices of this leaf                         */
+    int length;
+} rt_bvhbox;
+
+typedef struct rt_mesh {                                     /* mesh, kernel.cu:559-575 (field order kept) */
+    rt_triangle *d_tri_arr;
+    rt_triangle *h_tri_arr;
+    int poly_count;
+    int bvhbox_count;        /* flat list of leaves after 10 median splits            */
+    int bvhLayer_count;      /* 10                                                    */
+    uint8_t has_normals;
+    rt_bvhbox *h_box;
+    rt_bvhbox *d_box;
+    int *indexes;
+} rt_mesh;
+
 typedef struct rt_buffer {                                   /* buffer, sprite.h:11-19 */
     float *data;             /* planar floats in [0,1]                                */
     int size;                /* bytes (Sprite.cpp:14)                                 */
@@ -108,7 +137,8 @@ typedef struct rt_object {                                   /* object, kernel.c
     rt_sphere *d_spheres;    /* what the kernel reads (:1333)                         */
     rt_cube *c1, *d_cubes;   /* cubes read by the kernel at kernel.cu:1344-1356, 1526-1536 */
     rt_plane *planes, *d_planes; /* planes, kernel.cu:1359-1372, 1513-1523            */
-    void *mesh1;             /* mesh  -- OUT OF SCOPE: must be NULL (bvhbox_count = 0) */
+    rt_mesh *mesh1;          /* triangle mesh + flat BVH (kernel.cu:1293-1328, 1475-1497);
+                                NULL = no mesh (the reference's bvhbox_count = 0)       */
     rt_sprite *texture;      /* :1240, read at :1643-1655                             */
     void *mat;               /* unused                                                */
     void **tot_mesh;
@@ -237,6 +267,13 @@ int rt_msvc_rand_sequence(unsigned int seed, int *out, int n);
  * kind 0 = object texture (512x512), kind 1 = sky (2048x1024).           */
 int rt_synth_texture_size(int kind, int *width, int *height);
 int rt_synth_texture(int kind, float *r, float *g, float *b);
+/* mesh(filename) (kernel.cu:575-747) + createBvhMesh (:752-937): OBJ text (v / vt / vn /
+ * f with a, a//c or a/b/c tokens, triangles and quads) -> triangles -> flat list of
+ * leaf boxes. Host memory only (d_* alias h_*); no GPU needed. Blank lines, which
+ * corrupt the reference's parser state, are skipped. NULL on failure.            */
+rt_mesh *rt_mesh_from_obj_text(const char *text);
+rt_mesh *rt_mesh_load_obj(const char *path);
+void rt_mesh_free(rt_mesh *m);
 /* sprite(file) without OpenCV: binary PPM (P6) -> planar float planes.    */
 int rt_load_ppm(const char *path, float **r, float **g, float **b, int *width, int *height);
 void rt_free_planes(float *r, float *g, float *b);
@@ -255,6 +292,7 @@ void rt_scene_destroy(rt_scene *s);
 int rt_scene_set_spheres(rt_scene *s, const rt_sphere *host_spheres, int n);
 int rt_scene_set_planes(rt_scene *s, const rt_plane *host_planes, int n);   /* SURVEY.md 8(f) row 2 */
 int rt_scene_set_cubes(rt_scene *s, const rt_cube *host_cubes, int n);
+int rt_scene_set_mesh(rt_scene *s, const rt_mesh *mesh);    /* NULL removes it; SURVEY.md 8(f) row 4 */
 int rt_scene_set_texture(rt_scene *s, const float *r, const float *g, const float *b, int w, int h);
 int rt_scene_set_sky(rt_scene *s, const rt_sphere *box, const float *r, const float *g,
                      const float *b, int w, int h);

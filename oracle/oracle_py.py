@@ -42,6 +42,10 @@ class OCube(C.Structure):
     _fields_ = [("vptr", C.c_void_p), ("orgin", OVec3), ("normals", OVec3 * 3), ("bounds", OVec3 * 2)]
 
 
+class OTriangle(C.Structure):
+    _fields_ = [("points", OVec3 * 3), ("normal", OVec3), ("vecNormal", OVec3 * 3), ("vt", (C.c_float * 2) * 3)]
+
+
 class OSprite(C.Structure):
     _fields_ = [("r", C.POINTER(C.c_float)), ("g", C.POINTER(C.c_float)), ("b", C.POINTER(C.c_float)),
                 ("width", C.c_int), ("height", C.c_int)]
@@ -54,7 +58,7 @@ class OFrame(C.Structure):
                 ("cam", OCamera), ("sky_box", C.POINTER(OSphere)), ("sky_tex", C.POINTER(OSprite)),
                 ("y0", C.c_int), ("y1", C.c_int), ("off_x", C.c_double), ("off_y", C.c_double),
                 ("cubes", C.POINTER(OCube)), ("cube_count", C.c_int),
-                ("planes", C.POINTER(OPlane)), ("plane_count", C.c_int)]
+                ("planes", C.POINTER(OPlane)), ("plane_count", C.c_int), ("mesh", C.c_void_p)]
 
 
 _libs = {}
@@ -103,6 +107,18 @@ def load(libm: bool = False):
     lib.oracle_make_plane.argtypes = [C.POINTER(OPlane)] + [cf] * 6
     lib.oracle_make_cube.restype = None
     lib.oracle_make_cube.argtypes = [C.POINTER(OCube)] + [cf] * 6
+    lib.oracle_mesh_from_obj.restype = C.c_void_p
+    lib.oracle_mesh_from_obj.argtypes = [C.c_char_p]
+    lib.oracle_mesh_free.restype = None
+    lib.oracle_mesh_free.argtypes = [C.c_void_p]
+    lib.oracle_mesh_counts.restype = ci
+    lib.oracle_mesh_counts.argtypes = [C.c_void_p, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+    lib.oracle_mesh_triangles.restype = C.POINTER(OTriangle)
+    lib.oracle_mesh_triangles.argtypes = [C.c_void_p]
+    lib.oracle_mesh_box.restype = ci
+    lib.oracle_mesh_box.argtypes = [C.c_void_p, ci, C.POINTER(cf), C.POINTER(cf), C.POINTER(C.POINTER(ci)), C.POINTER(ci)]
+    lib.oracle_triangle_intersect.restype = ci
+    lib.oracle_triangle_intersect.argtypes = [C.POINTER(OTriangle), C.POINTER(ORay), C.POINTER(cf), C.POINTER(cf), C.POINTER(cf)]
     lib.oracle_msvc_srand.restype = None
     lib.oracle_msvc_srand.argtypes = [C.c_uint]
     lib.oracle_msvc_rand.restype = ci
@@ -134,7 +150,7 @@ def make_sprite(planes):
 
 def render(spheres, n_spheres, texture_planes, sky_planes, sky_box, lights, n_lights, cam, width, height,
            aspect, y0=0, y1=None, off=(0.5, 0.5), nthreads=1, libm=False, want_rgba=True,
-           cubes=None, n_cubes=0, planes=None, n_planes=0):
+           cubes=None, n_cubes=0, planes=None, n_planes=0, mesh=None):
     """Run the oracle on the given inputs. `spheres`/`lights`/`cam`/`sky_box` may be
     the product's ctypes arrays: they are byte-copied into the oracle's own PODs.
     Returns (rgba float32 [rows,W,4], packed uint32 [rows,W], counters dict)."""
@@ -157,7 +173,7 @@ def render(spheres, n_spheres, texture_planes, sky_planes, sky_box, lights, n_li
     if n_planes:
         C.memmove(oplanes, planes, 40 * n_planes)
     fr = OFrame(width, height, aspect, osph, n_spheres, C.pointer(tex), olights, n_lights, ocam,
-                C.pointer(obox), C.pointer(sky), y0, y1, off[0], off[1], ocubes, n_cubes, oplanes, n_planes)
+                C.pointer(obox), C.pointer(sky), y0, y1, off[0], off[1], ocubes, n_cubes, oplanes, n_planes, mesh)
     rows = y1 - y0
     rgba = np.zeros((rows, width, 4), dtype=np.float32) if want_rgba else None
     packed = np.zeros((rows, width), dtype=np.uint32)
@@ -168,3 +184,29 @@ def render(spheres, n_spheres, texture_planes, sky_planes, sky_box, lights, n_li
         raise RuntimeError("oracle_render rejected the frame")
     counters = {"primary_tests": cnt[0], "shadow_tests": cnt[1], "hit_pixels": cnt[2], "unshadowed": cnt[3]}
     return rgba, packed, counters
+
+
+class Mesh:
+    """The oracle's restatement of the reference mesh loader + BVH on OBJ text."""
+
+    def __init__(self, obj_text: str, libm: bool = False):
+        self.lib = load(libm)
+        self.handle = self.lib.oracle_mesh_from_obj(obj_text.encode())
+        if not self.handle:
+            raise ValueError("OBJ text produced no triangles")
+        pc, bc, hn = C.c_int(), C.c_int(), C.c_int()
+        self.lib.oracle_mesh_counts(self.handle, C.byref(pc), C.byref(bc), C.byref(hn))
+        self.poly_count, self.bvhbox_count, self.has_normals = pc.value, bc.value, bool(hn.value)
+
+    def triangles(self):
+        ptr = self.lib.oracle_mesh_triangles(self.handle)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(self.poly_count, 27)).copy()
+
+    def boxes(self):
+        out = []
+        for j in range(self.bvhbox_count):
+            b, o = (C.c_float * 6)(), (C.c_float * 3)()
+            idx, ln = C.POINTER(C.c_int)(), C.c_int()
+            self.lib.oracle_mesh_box(self.handle, j, b, o, C.byref(idx), C.byref(ln))
+            out.append((list(b), list(o), [idx[i] for i in range(ln.value)]))
+        return out

@@ -17,6 +17,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -219,6 +220,8 @@ void oracle_make_cube(o_cube *c, float ax, float ay, float az, float bx, float b
     c->normals[0].x = 1; c->normals[1].y = 1; c->normals[2].z = 1;   /* kernel.cu:507 */
 }
 
+#include "rt_oracle_mesh.inc"
+
 /* ---- rgbToInt, kernel.cu:547-556 ---- */
 uint32_t oracle_rgb_to_int(int r, int g, int b)
 {
@@ -268,7 +271,29 @@ static int castRay(const ctx_t *cx, const ray *cam_ray, int *hit_index, float *n
 {
     const o_frame *f = cx->f;
     int hit_type = 1;
+    float nu = 0, nv = 0;
     *nt = INFINITY;
+
+    /* triangles through the flat box list, kernel.cu:1293-1328 */
+    if (f->mesh)
+        for (int j = 0; j < f->mesh->bvhbox_count; j++) {
+            float temp;
+            if (cube_intersect(&f->mesh->boxes[j].box, cam_ray, &temp)) {
+                for (int i = 0; i < f->mesh->boxes[j].length; i++) {
+                    float t, u, v;
+                    int idx = f->mesh->boxes[j].indexes[i];
+                    if (rayIntersect(cam_ray, &f->mesh->tris[idx], &t, &u, &v)) {
+                        if (t < *nt) {
+                            *nt = t;
+                            nv = v;
+                            nu = u;
+                            *hit_index = idx;
+                            hit_type = 0;
+                        }
+                    }
+                }
+            }
+        }
 
     for (int i = 0; i < f->sphere_count; i++) {
         float t;
@@ -305,6 +330,25 @@ static int castRay(const ctx_t *cx, const ray *cam_ray, int *hit_index, float *n
     }
 
     if (*nt != INFINITY) {
+        if (hit_type == 0) {            /* kernel.cu:1378-1393 */
+            const o_triangle *tr = &f->mesh->tris[*hit_index];
+            if (f->mesh->has_normals) {
+                vec3d a = multiplyf(tr->vecNormal[0], (1 - nu - nv));
+                vec3d b = multiplyf(tr->vecNormal[1], nu);
+                vec3d c = multiplyf(tr->vecNormal[2], nv);
+                vec3d ab = add(&a, &b);
+                *normal = add(&ab, &c);
+                *normal = normalise(normal);
+            } else {
+                *normal = tr->normal;
+            }
+            *tx = ((1 - nu - nv) * tr->vt[0][0]) + (nu * tr->vt[1][0]) + (nv * tr->vt[2][0]);
+            *ty = ((1 - nu - nv) * tr->vt[0][1]) + (nu * tr->vt[1][1]) + (nv * tr->vt[2][1]);
+            /* new_org = add(normal, add(Org, Dir*nt)): offset by the WHOLE normal */
+            vec3d step = multiplyf(cam_ray->Dir, *nt);
+            vec3d hp = add(&cam_ray->Org, &step);
+            *new_org = add(normal, &hp);
+        }
         if (hit_type == 1) {            /* kernel.cu:1396-1405 */
             vec3d step = multiplyf(cam_ray->Dir, *nt);
             *new_org = add(&cam_ray->Org, &step);
@@ -335,8 +379,18 @@ static int castRay(const ctx_t *cx, const ray *cam_ray, int *hit_index, float *n
 }
 
 /* ---- castLightRay, sphere branch: kernel.cu:1433-1471, 1499-1510, 1537-1544 ---- */
+static float castLightRay_impl3(const o_mesh *mesh, const o_sphere *spheres, int sphere_count, const o_plane *planes,
+                                int plane_count, const o_cube *cubes, int cube_count, const vec3d *start,
+                                const o_light *l, const vec3d *normal, counters_t *cnt, float *dirs_out);
 static float castLightRay_impl2(const o_sphere *spheres, int sphere_count, const o_plane *planes, int plane_count,
                                 const o_cube *cubes, int cube_count, const vec3d *start,
+                                const o_light *l, const vec3d *normal, counters_t *cnt, float *dirs_out)
+{
+    return castLightRay_impl3(NULL, spheres, sphere_count, planes, plane_count, cubes, cube_count, start, l, normal,
+                              cnt, dirs_out);
+}
+static float castLightRay_impl3(const o_mesh *mesh, const o_sphere *spheres, int sphere_count, const o_plane *planes,
+                                int plane_count, const o_cube *cubes, int cube_count, const vec3d *start,
                                 const o_light *l, const vec3d *normal, counters_t *cnt, float *dirs_out)
 {
     float b = 0;
@@ -379,6 +433,23 @@ static float castLightRay_impl2(const o_sphere *spheres, int sphere_count, const
         if (dirs_out) { dirs_out[3 * j] = new_dir.x; dirs_out[3 * j + 1] = new_dir.y; dirs_out[3 * j + 2] = new_dir.z; }
 
         shadow = 0;
+
+        /* triangles, kernel.cu:1475-1497 (the reference reads Bvhbox::bvhbox there, a
+         * managed copy of the same cube as d_bvhbox) */
+        if (mesh)
+            for (int bj = 0; bj < mesh->bvhbox_count; bj++) {
+                float temp;
+                if (cube_intersect(&mesh->boxes[bj].box, &light_ray, &temp)) {
+                    for (int i = 0; i < mesh->boxes[bj].length; i++) {
+                        float t, u, v;
+                        if (rayIntersect(&light_ray, &mesh->tris[mesh->boxes[bj].indexes[i]], &t, &u, &v)) {
+                            shadow = 1;
+                            break;
+                        }
+                    }
+                    if (shadow) break;
+                }
+            }
 
         if (!shadow)
             for (int i = 0; i < sphere_count; i++) {
@@ -530,7 +601,7 @@ static void trace_pixel(const ctx_t *cx, int x, int y, float *rgba, uint32_t *pa
 
         float fr = 0, fg = 0, fb = 0;
         for (int i = 0; i < f->light_size; i++) {
-            float brightness = castLightRay_impl2(f->spheres, f->sphere_count, f->planes, f->plane_count,
+            float brightness = castLightRay_impl3(f->mesh, f->spheres, f->sphere_count, f->planes, f->plane_count,
                                                   f->cubes, f->cube_count, &start_O,
                                                   &f->lights[i], &obj_normal, cx->cnt, NULL);
             fr += brightness * f->lights[i].r * r;

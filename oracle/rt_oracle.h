@@ -49,6 +49,13 @@ typedef struct {                                            /* cube : shape, ker
     o_vec3d normals[3];       /* @20 */
     o_vec3d bounds[2];        /* @56 */
 } o_cube;                                                   /* 80 bytes */
+typedef struct {                                            /* triangle, kernel.cu:206-212 */
+    o_vec3d points[3];
+    o_vec3d normal;           /* face normal, normalise(cross(p1-p0, p2-p0)) */
+    o_vec3d vecNormal[3];
+    float vt[3][2];           /* vec2d {u, v} */
+} o_triangle;                                               /* 108 bytes (mesh::getBytes, kernel.cu:1018-1020) */
+typedef struct o_mesh o_mesh;                               /* mesh, kernel.cu:559-1113 */
 typedef struct {                                            /* sprite.h:25-47 */
     const float *r, *g, *b; /* rBuff/gBuff/bBuff ->data : planar floats in [0,1] */
     int width, height;
@@ -73,6 +80,7 @@ typedef struct {
     int cube_count;
     const o_plane *planes;    /* objs.d_planes (kernel.cu:1359-1372) */
     int plane_count;
+    const o_mesh *mesh;       /* objs.mesh1 (kernel.cu:1293-1328, 1475-1497); NULL = bvhbox_count 0 */
 } o_frame;
 
 /* counters[0]=primary sphere tests, [1]=shadow sphere tests,
@@ -96,6 +104,15 @@ int oracle_plane_intersect(const o_plane *p, const o_ray *r, float *t);  /* kern
 int oracle_cube_intersect(const o_cube *c, const o_ray *r, float *t);    /* kernel.cu:400-485 */
 void oracle_make_plane(o_plane *p, float px, float py, float pz, float nx, float ny, float nz); /* :364-367 */
 void oracle_make_cube(o_cube *c, float ax, float ay, float az, float bx, float by, float bz);   /* :391-396 */
+/* mesh: OBJ text -> triangles (loader, kernel.cu:575-747) -> flat BVH (createBvhMesh, :752-937).
+ * Restated for well-formed OBJ text; lines the reference mis-parses (blank lines leave its
+ * stream state stale) are skipped instead -- documented deviation. */
+o_mesh *oracle_mesh_from_obj(const char *text);
+void oracle_mesh_free(o_mesh *m);
+int oracle_mesh_counts(const o_mesh *m, int *poly_count, int *bvhbox_count, int *has_normals);
+const o_triangle *oracle_mesh_triangles(const o_mesh *m);
+int oracle_mesh_box(const o_mesh *m, int j, float bounds[6], float orgin[3], const int **indexes, int *length);
+int oracle_triangle_intersect(const o_triangle *tri, const o_ray *r, float *t, float *u, float *v); /* :1024-1059 */
 /* MSVC rand() replay + scene generator (kernel.cu:1189-1192). */
 void oracle_msvc_srand(unsigned int seed);
 int oracle_msvc_rand(void);

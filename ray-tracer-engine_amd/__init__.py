@@ -76,6 +76,25 @@ class Cube(C.Structure):
     _fields_ = [("vptr_slot", C.c_void_p), ("orgin", Vec3), ("normals", Vec3 * 3), ("bounds", Vec3 * 2)]
 
 
+class Vec2(C.Structure):
+    _fields_ = [("u", C.c_float), ("v", C.c_float)]
+
+
+class Triangle(C.Structure):
+    _fields_ = [("points", Vec3 * 3), ("normal", Vec3), ("vecNormal", Vec3 * 3), ("vt", Vec2 * 3)]
+
+
+class BvhBox(C.Structure):
+    _fields_ = [("bvhbox", C.POINTER(Cube)), ("d_bvhbox", C.POINTER(Cube)), ("indexes", C.POINTER(C.c_int)),
+                ("d_indexes", C.POINTER(C.c_int)), ("length", C.c_int)]
+
+
+class Mesh(C.Structure):
+    _fields_ = [("d_tri_arr", C.POINTER(Triangle)), ("h_tri_arr", C.POINTER(Triangle)), ("poly_count", C.c_int),
+                ("bvhbox_count", C.c_int), ("bvhLayer_count", C.c_int), ("has_normals", C.c_uint8),
+                ("h_box", C.POINTER(BvhBox)), ("d_box", C.POINTER(BvhBox)), ("indexes", C.POINTER(C.c_int))]
+
+
 class Buffer(C.Structure):
     _fields_ = [("data", C.POINTER(C.c_float)), ("size", C.c_int)]
 
@@ -93,7 +112,7 @@ class Object(C.Structure):
     _fields_ = [("sphere_count", C.c_int), ("plane_count", C.c_int), ("cube_count", C.c_int),
                 ("depth", C.c_int), ("s1", C.POINTER(Sphere)), ("d_spheres", C.POINTER(Sphere)),
                 ("c1", C.POINTER(Cube)), ("d_cubes", C.POINTER(Cube)), ("planes", C.POINTER(Plane)),
-                ("d_planes", C.POINTER(Plane)), ("mesh1", C.c_void_p), ("texture", C.POINTER(Sprite)),
+                ("d_planes", C.POINTER(Plane)), ("mesh1", C.POINTER(Mesh)), ("texture", C.POINTER(Sprite)),
                 ("mat", C.c_void_p), ("tot_mesh", C.c_void_p), ("meshes", C.c_int)]
 
 
@@ -153,6 +172,10 @@ def load_library():
         "rt_offscreen_write_ppm": (ci, [C.c_char_p]),
         "rt_sphere_init": (None, [C.POINTER(Sphere), cf, cf, cf, cf]),
         "rt_generate_spheres": (ci, [C.POINTER(Sphere), ci, C.c_uint]),
+        "rt_mesh_from_obj_text": (C.POINTER(Mesh), [C.c_char_p]),
+        "rt_mesh_load_obj": (C.POINTER(Mesh), [C.c_char_p]),
+        "rt_mesh_free": (None, [C.POINTER(Mesh)]),
+        "rt_scene_set_mesh": (ci, [vp, C.POINTER(Mesh)]),
         "rt_plane_init": (None, [C.POINTER(Plane), cf, cf, cf, cf, cf, cf]),
         "rt_cube_init": (None, [C.POINTER(Cube), cf, cf, cf, cf, cf, cf]),
         "rt_scene_set_planes": (ci, [vp, C.POINTER(Plane), ci]),
@@ -230,6 +253,15 @@ def synth_texture(kind: int):
     return planes
 
 
+def mesh_from_obj_text(text: str):
+    """rt_mesh* (reference layout) from OBJ text; raises on failure."""
+    lib = load_library()
+    m = lib.rt_mesh_from_obj_text(text.encode())
+    if not m:
+        raise RtError("rt_mesh_from_obj_text: " + lib.rt_last_error().decode(errors="replace"))
+    return m
+
+
 def sky_sphere(size: float = 10000.0) -> Sphere:
     s = Sphere()
     load_library().rt_sphere_init(C.byref(s), 0.0, 0.0, 0.0, size)
@@ -296,6 +328,10 @@ class Scene:
     def set_cubes(self, cubes, n):
         _check(self.lib.rt_scene_set_cubes(self.handle, cubes, n), "rt_scene_set_cubes")
         self.cubes, self.n_cubes = cubes, n
+
+    def set_mesh(self, mesh):
+        _check(self.lib.rt_scene_set_mesh(self.handle, mesh), "rt_scene_set_mesh")
+        self.mesh = mesh
 
     def set_texture(self, planes):
         planes = [np.ascontiguousarray(p, dtype=np.float32) for p in planes]

@@ -48,6 +48,18 @@ struct RtCubeDev {      // cube: the two corners and (c1+c2)/2 (kernel.cu:391-39
     float ax, ay, az, bx, by, bz, cx, cy, cz, pad0_, pad1_, pad2_;
 };
 
+struct RtTriDev {       // triangle, kernel.cu:206-212, padded to 28 floats
+    float p0[3], p1[3], p2[3];
+    float n[3];
+    float vn[9];
+    float vt[6];
+    float pad_;
+};
+struct RtBoxDev {       // one leaf of the flat BVH: bounds + its slice of the index array
+    float lo[3], hi[3];
+    int start, len;
+};
+
 struct RtFrameConsts {
     // frame / band geometry
     int width, height;          // full frame (ray generation uses these)
@@ -91,6 +103,12 @@ struct RtFrameConsts {
     const RtPlaneDev *planes;
     const RtCubeDev *cubes;
     int n_planes, n_cubes;
+
+    // triangle mesh behind a flat list of leaf boxes
+    const RtTriDev *tris;
+    const RtBoxDev *boxes;
+    const int *tri_idx;
+    int n_boxes, mesh_has_normals;
 
     // outputs
     float *rgba;                // float4 per pixel, band-local, may be null

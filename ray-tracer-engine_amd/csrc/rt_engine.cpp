@@ -123,6 +123,10 @@ struct rt_scene {
     RtPlaneDev *d_planes = nullptr;
     RtCubeDev *d_cubes = nullptr;
     int n_planes = 0, n_cubes = 0;
+    RtTriDev *d_tris = nullptr;
+    RtBoxDev *d_boxes = nullptr;
+    int *d_tri_idx = nullptr;
+    int n_boxes = 0, n_tris = 0, mesh_has_normals = 0;
 };
 
 // Largest table a workgroup can stage in LDS next to its lists, and the size up
@@ -158,6 +162,9 @@ extern "C" void rt_scene_destroy(rt_scene *s)
     free_planes(s->d_sky);
     if (s->d_planes) (void)hipFree(s->d_planes);
     if (s->d_cubes) (void)hipFree(s->d_cubes);
+    if (s->d_tris) (void)hipFree(s->d_tris);
+    if (s->d_boxes) (void)hipFree(s->d_boxes);
+    if (s->d_tri_idx) (void)hipFree(s->d_tri_idx);
     delete s;
 }
 
@@ -253,6 +260,69 @@ extern "C" int rt_scene_set_cubes(rt_scene *s, const rt_cube *host_cubes, int n)
     }
     if (n) RT_HIP(hipMemcpy(s->d_cubes, tmp.data(), sizeof(RtCubeDev) * n, hipMemcpyHostToDevice));
     s->n_cubes = n;
+    return RT_OK;
+}
+
+// Flatten the reference-layout mesh (triangles, leaf boxes with their own index
+// arrays) into three device arrays: triangles, boxes {bounds, start, len}, indices.
+extern "C" int rt_scene_set_mesh(rt_scene *s, const rt_mesh *mesh)
+{
+    if (!s) {
+        rt_set_error("rt_scene_set_mesh: null scene");
+        return RT_ERR_INVALID;
+    }
+    if (s->d_tris) RT_HIP(hipFree(s->d_tris));
+    if (s->d_boxes) RT_HIP(hipFree(s->d_boxes));
+    if (s->d_tri_idx) RT_HIP(hipFree(s->d_tri_idx));
+    s->d_tris = nullptr; s->d_boxes = nullptr; s->d_tri_idx = nullptr;
+    s->n_boxes = s->n_tris = 0;
+    if (!mesh || mesh->bvhbox_count == 0) return RT_OK;
+    if (mesh->poly_count <= 0 || mesh->bvhbox_count < 0 || !mesh->d_tri_arr || !mesh->d_box) {
+        rt_set_error("rt_scene_set_mesh: malformed mesh (poly_count=%d bvhbox_count=%d)", mesh->poly_count,
+                     mesh->bvhbox_count);
+        return RT_ERR_INVALID;
+    }
+    std::vector<RtTriDev> tris((size_t)mesh->poly_count);
+    for (int i = 0; i < mesh->poly_count; ++i) {
+        const rt_triangle &t = mesh->d_tri_arr[i];
+        RtTriDev &d = tris[i];
+        memset(&d, 0, sizeof d);
+        memcpy(d.p0, &t.points[0], 12); memcpy(d.p1, &t.points[1], 12); memcpy(d.p2, &t.points[2], 12);
+        memcpy(d.n, &t.normal, 12);
+        memcpy(d.vn, t.vecNormal, 36);
+        memcpy(d.vt, t.vt, 24);
+    }
+    std::vector<RtBoxDev> boxes((size_t)mesh->bvhbox_count);
+    std::vector<int> idx;
+    for (int j = 0; j < mesh->bvhbox_count; ++j) {
+        const rt_bvhbox &b = mesh->d_box[j];
+        const rt_cube *c = b.d_bvhbox ? b.d_bvhbox : b.bvhbox;
+        if (!c || !b.d_indexes || b.length < 0) {
+            rt_set_error("rt_scene_set_mesh: leaf %d is incomplete", j);
+            return RT_ERR_INVALID;
+        }
+        RtBoxDev &d = boxes[j];
+        d.lo[0] = c->bounds[0].x; d.lo[1] = c->bounds[0].y; d.lo[2] = c->bounds[0].z;
+        d.hi[0] = c->bounds[1].x; d.hi[1] = c->bounds[1].y; d.hi[2] = c->bounds[1].z;
+        d.start = (int)idx.size();
+        d.len = b.length;
+        for (int i = 0; i < b.length; ++i) {
+            if (b.d_indexes[i] < 0 || b.d_indexes[i] >= mesh->poly_count) {
+                rt_set_error("rt_scene_set_mesh: leaf %d references triangle %d of %d", j, b.d_indexes[i], mesh->poly_count);
+                return RT_ERR_INVALID;
+            }
+            idx.push_back(b.d_indexes[i]);
+        }
+    }
+    RT_HIP(hipMalloc((void **)&s->d_tris, sizeof(RtTriDev) * tris.size()));
+    RT_HIP(hipMalloc((void **)&s->d_boxes, sizeof(RtBoxDev) * boxes.size()));
+    RT_HIP(hipMalloc((void **)&s->d_tri_idx, sizeof(int) * (idx.size() ? idx.size() : 1)));
+    RT_HIP(hipMemcpy(s->d_tris, tris.data(), sizeof(RtTriDev) * tris.size(), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(s->d_boxes, boxes.data(), sizeof(RtBoxDev) * boxes.size(), hipMemcpyHostToDevice));
+    if (!idx.empty()) RT_HIP(hipMemcpy(s->d_tri_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
+    s->n_boxes = mesh->bvhbox_count;
+    s->n_tris = mesh->poly_count;
+    s->mesh_has_normals = mesh->has_normals ? 1 : 0;
     return RT_OK;
 }
 
@@ -361,7 +431,7 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
                      total, RT_MAX_SPP);
         return RT_ERR_INVALID;
     }
-    if ((s->n_spheres > 0 || s->n_planes > 0 || s->n_cubes > 0) && (!s->d_tex[0] || s->tex_w <= 0)) {
+    if ((s->n_spheres > 0 || s->n_planes > 0 || s->n_cubes > 0 || s->n_boxes > 0) && (!s->d_tex[0] || s->tex_w <= 0)) {
         rt_set_error("rt_scene_render: scene has primitives but no object texture");
         return RT_ERR_INVALID;
     }
@@ -482,6 +552,11 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
     fc->cubes = s->d_cubes;
     fc->n_planes = s->n_planes;
     fc->n_cubes = s->n_cubes;
+    fc->tris = s->d_tris;
+    fc->boxes = s->d_boxes;
+    fc->tri_idx = s->d_tri_idx;
+    fc->n_boxes = s->n_boxes;
+    fc->mesh_has_normals = s->mesh_has_normals;
     fc->rgba = o.rgba;
     fc->packed = fd->pixels;
     fc->stats = (unsigned long long *)o.stats;
@@ -508,6 +583,10 @@ extern "C" int rt_scene_render(rt_scene *s, const rt_frame_desc *fd, void *strea
     rc = tile_from_opts(fd->opts, &tile);
     if (rc != RT_OK) return rc;
     if (fc.local_rows == 0) return RT_OK;   // this rank owns no rows of the frame
+    if (fc.n_boxes > 0 && (tile != 8 || fd->opts.stats)) {
+        rt_set_error("rt_scene_render: scenes with a triangle mesh render with the default tile and without stats");
+        return RT_ERR_UNSUPPORTED;
+    }
     const int cull = (fd->opts.cull == 0) ? 0 : 1;
     const int stats = fd->opts.stats ? (fd->opts.profile ? 2 : 1) : 0;
     RT_HIP(rt_dev_launch_trace(&fc, s->d_spheres, tile, cull, stats, table_in_lds_for(s->n_spheres), (hipStream_t)stream));
@@ -520,6 +599,8 @@ extern "C" int rt_scene_render(rt_scene *s, const rt_frame_desc *fd, void *strea
 // ---------------------------------------------------------------------------
 struct ShimCache {
     rt_scene *scene = nullptr;
+    const rt_mesh *mesh_key = nullptr;
+    int mesh_polys = -1, mesh_boxes = -1;
     const float *tex_key[3] = {nullptr, nullptr, nullptr};
     int tex_w = 0, tex_h = 0;
     const float *sky_key[3] = {nullptr, nullptr, nullptr};
@@ -531,6 +612,8 @@ static ShimCache g_shim;
 
 extern "C" void rt_invalidate_textures(void)
 {
+    g_shim.mesh_key = nullptr;
+    g_shim.mesh_polys = g_shim.mesh_boxes = -1;
     g_shim.tex_key[0] = g_shim.tex_key[1] = g_shim.tex_key[2] = nullptr;
     g_shim.sky_key[0] = g_shim.sky_key[1] = g_shim.sky_key[2] = nullptr;
 }
@@ -550,11 +633,6 @@ extern "C" int rt_launch_raytrace_ex(uint32_t *pixels, int width, int height, fl
         rt_set_error("rt_launch_raytrace: null objs/lights/sky");
         return RT_ERR_INVALID;
     }
-    // Out-of-scope primitive: the triangle mesh / BVH.
-    if (objs->mesh1 != nullptr) {
-        rt_set_error("rt_launch_raytrace: triangle meshes are outside this library's path (mesh1=%p)", objs->mesh1);
-        return RT_ERR_UNSUPPORTED;
-    }
     if (objs->cube_count < 0 || objs->plane_count < 0 || (objs->cube_count > 0 && !objs->d_cubes) ||
         (objs->plane_count > 0 && !objs->d_planes)) {
         rt_set_error("rt_launch_raytrace: bad cube/plane list");
@@ -568,7 +646,8 @@ extern "C" int rt_launch_raytrace_ex(uint32_t *pixels, int width, int height, fl
         rt_set_error("rt_launch_raytrace: skybox needs a box sphere and a texture");
         return RT_ERR_INVALID;
     }
-    if ((objs->sphere_count > 0 || objs->cube_count > 0 || objs->plane_count > 0) && !sprite_ok(objs->texture)) {
+    if ((objs->sphere_count > 0 || objs->cube_count > 0 || objs->plane_count > 0 || objs->mesh1) &&
+        !sprite_ok(objs->texture)) {
         rt_set_error("rt_launch_raytrace: object texture missing");
         return RT_ERR_INVALID;
     }
@@ -576,7 +655,7 @@ extern "C" int rt_launch_raytrace_ex(uint32_t *pixels, int width, int height, fl
     rt_scene *s = g_shim.scene;
     int rc;
     // textures: uploaded once per (planes, size); see rt_invalidate_textures()
-    if (objs->sphere_count > 0 || objs->cube_count > 0 || objs->plane_count > 0) {
+    if (objs->sphere_count > 0 || objs->cube_count > 0 || objs->plane_count > 0 || objs->mesh1) {
         const rt_sprite *t = objs->texture;
         if (t->rBuff->data != g_shim.tex_key[0] || t->gBuff->data != g_shim.tex_key[1] ||
             t->bBuff->data != g_shim.tex_key[2] || t->width != g_shim.tex_w || t->height != g_shim.tex_h) {
@@ -598,6 +677,18 @@ extern "C" int rt_launch_raytrace_ex(uint32_t *pixels, int width, int height, fl
             g_shim.sky_w = t->width; g_shim.sky_h = t->height;
             g_shim.sky_c[0] = sky->box->orgin.x; g_shim.sky_c[1] = sky->box->orgin.y; g_shim.sky_c[2] = sky->box->orgin.z;
             g_shim.sky_radius = sky->box->radius;
+        }
+    }
+    // the mesh is uploaded once per (pointer, counts), like the textures
+    {
+        const rt_mesh *m = (objs->mesh1 && objs->mesh1->bvhbox_count > 0) ? objs->mesh1 : nullptr;
+        const int polys = m ? m->poly_count : 0, boxes = m ? m->bvhbox_count : 0;
+        if (m != g_shim.mesh_key || polys != g_shim.mesh_polys || boxes != g_shim.mesh_boxes) {
+            rc = rt_scene_set_mesh(s, m);
+            if (rc != RT_OK) return rc;
+            g_shim.mesh_key = m;
+            g_shim.mesh_polys = polys;
+            g_shim.mesh_boxes = boxes;
         }
     }
     // spheres and lights are small and may change every frame: re-mirror them

@@ -223,6 +223,38 @@ __device__ __forceinline__ bool cube_intersect(const RtCubeDev &c, V3 o, V3 inv,
     return true;
 }
 
+// mesh::rayIntersect (Moller-Trumbore), kernel.cu:1024-1059. The two double
+// literals there (`a < 0.0000001`, `t > 0.0000001`) compare the widened float
+// with 1e-7; 1e-7f is the smallest binary32 >= 1e-7, so `a < 1e-7f` and
+// `t >= 1e-7f` are the same predicates.
+__device__ __forceinline__ bool tri_intersect(V3 o, V3 d, const float *p0, const float *p1, const float *p2,
+                                              float &t, float &u, float &v)
+{
+    const V3 e1{p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+    const V3 e2{p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+    const V3 h{d.y * e2.z - d.z * e2.y, d.z * e2.x - d.x * e2.z, d.x * e2.y - d.y * e2.x};
+    const float a = dot3(e1, h);
+    if (a > -0.0000001f && a < 0.0000001f) return false;
+    const float f = 1.f / a;
+    const V3 s{o.x - p0[0], o.y - p0[1], o.z - p0[2]};
+    u = f * dot3(s, h);
+    if (u < 0.f || u > 1.f) return false;
+    const V3 q{s.y * e1.z - s.z * e1.y, s.z * e1.x - s.x * e1.z, s.x * e1.y - s.y * e1.x};
+    v = f * dot3(d, q);
+    if (v < 0.f || u + v > 1.f) return false;
+    t = f * dot3(e2, q);
+    return t >= 0.0000001f;
+}
+
+__device__ __forceinline__ bool box_intersect(const RtBoxDev &b, V3 o, V3 inv)
+{
+    RtCubeDev c;
+    c.ax = b.lo[0]; c.ay = b.lo[1]; c.az = b.lo[2];
+    c.bx = b.hi[0]; c.by = b.hi[1]; c.bz = b.hi[2];
+    float t;
+    return cube_intersect(c, o, inv, t);
+}
+
 // A ray that starts outside a sphere whose centre lies behind it has B > 0 and
 // disc < B*B; then sqrt(disc) < B, t < 0 strictly and intersect() is false. The
 // factor keeps sqrt(disc) below B even after rounding, so the `t == 0` clause
@@ -443,7 +475,7 @@ __device__ __forceinline__ void shadow_test(const RayK &sr, float4 s, bool &shad
 // ---------------------------------------------------------------------------
 // STATS: 0 = product kernel, 1 = work counters, 2 = per-phase cycle stamps
 // (s_memtime; a diagnostic build whose run time is never quoted).
-template <int TW, bool CULL, int STATS, bool TABLDS>
+template <int TW, bool CULL, int STATS, bool TABLDS, bool MESH = false>
 __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void rt_trace_tiles(const RtFrameConsts fc,
                                                                      const float4 *__restrict__ spheres)
 {
@@ -554,6 +586,32 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
         phase(1);
         float nt = __builtin_inff();
         float hcx = 0.f, hcy = 0.f, hcz = 0.f;   // centre of the closest sphere
+        int hkind = 1;                           // 0 triangle, 1 sphere, 2 plane, 3 cube (kernel.cu:1376)
+        int htri = 0;
+        float hnu = 0.f, hnv = 0.f;
+        if (MESH) {
+            // triangles through the flat list of leaf boxes, kernel.cu:1293-1328 (before
+            // the spheres, as there): a lane tests a leaf's triangles iff its ray hits the box
+            const V3 inv{1.f / D.x, 1.f / D.y, 1.f / D.z};
+            for (int j = 0; j < fc.n_boxes; ++j) {
+                const RtBoxDev bx = fc.boxes[j];
+                const bool bh = box_intersect(bx, O, inv);
+                if (__any(bh)) {
+                    for (int i = 0; i < bx.len; ++i) {
+                        const int idx = fc.tri_idx[bx.start + i];
+                        const RtTriDev *tp = fc.tris + idx;
+                        float t, u, v;
+                        if (bh && tri_intersect(O, D, tp->p0, tp->p1, tp->p2, t, u, v) && t < nt) {
+                            nt = t;
+                            hnu = u;
+                            hnv = v;
+                            htri = idx;
+                            hkind = 0;
+                        }
+                    }
+                }
+            }
+        }
         float4 pcur = pcount > 0 ? entry_at<TABLDS>(p_use_list, mylist, tab, spheres, 0) : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int e = 0; e < pcount; ++e) {
             const float4 s = pcur;
@@ -569,6 +627,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                         if (t < nt) {   // strict: first index wins ties (kernel.cu:1335)
                             nt = t;
                             hcx = s.x; hcy = s.y; hcz = s.z;
+                            if (MESH) hkind = 1;
                         }
                     }
                 }
@@ -578,7 +637,6 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
         if (CULL) wave_lds_sync();   // the list is rebuilt below
         // cubes (kernel.cu:1344-1356) then planes (:1359-1372): few, tested exhaustively;
         // for a plane hit hc* carries the plane's normal instead of a centre
-        int hkind = 1;
         if (fc.n_cubes > 0) {
             const V3 inv{1.f / D.x, 1.f / D.y, 1.f / D.z};
             for (int i = 0; i < fc.n_cubes; ++i) {
@@ -628,7 +686,24 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
         if (hit) {
             const V3 new_org{O.x + D.x * nt, O.y + D.y * nt, O.z + D.z * nt};
             float tx = 0.5f, ty = 0.5f;   // plane, kernel.cu:1413-1414
-            if (hkind == 2) {             // plane, kernel.cu:1407-1416: the normal as stored
+            V3 hp = new_org;              // what start_O is offset from
+            if (MESH && hkind == 0) {     // triangle, kernel.cu:1378-1393
+                const RtTriDev *tp = fc.tris + htri;
+                const float w0 = 1 - hnu - hnv;
+                if (fc.mesh_has_normals) {
+                    normal = V3{(tp->vn[0] * w0 + tp->vn[3] * hnu) + tp->vn[6] * hnv,
+                                (tp->vn[1] * w0 + tp->vn[4] * hnu) + tp->vn[7] * hnv,
+                                (tp->vn[2] * w0 + tp->vn[5] * hnu) + tp->vn[8] * hnv};
+                    normalise_inplace(normal);
+                } else {
+                    normal = V3{tp->n[0], tp->n[1], tp->n[2]};
+                }
+                tx = (w0 * tp->vt[0]) + (hnu * tp->vt[2]) + (hnv * tp->vt[4]);
+                ty = (w0 * tp->vt[1]) + (hnu * tp->vt[3]) + (hnv * tp->vt[5]);
+                // new_org = add(normal, add(Org, Dir * nt)): displaced by the whole normal
+                hp = V3{normal.x + new_org.x, normal.y + new_org.y, normal.z + new_org.z};
+                hcx = hcy = hcz = 0.f;    // one group for all triangle hits of the tile
+            } else if (hkind == 2) {      // plane, kernel.cu:1407-1416: the normal as stored
                 normal = V3{hcx, hcy, hcz};
             } else {                      // sphere / cube, kernel.cu:1396-1405, 1418-1425
                 normal = V3{new_org.x - hcx, new_org.y - hcy, new_org.z - hcz};
@@ -648,8 +723,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
             tg = fc.tex_g[ci];
             tb = fc.tex_b[ci];
             // start_O = normal * 0.00001 + new_org, kernel.cu:1647
-            start = V3{normal.x * 0.00001f + new_org.x, normal.y * 0.00001f + new_org.y,
-                       normal.z * 0.00001f + new_org.z};
+            start = V3{normal.x * 0.00001f + hp.x, normal.y * 0.00001f + hp.y, normal.z * 0.00001f + hp.z};
             if (STATS == 1) st_hits += 1;
         }
 
@@ -824,7 +898,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                 // needed for kernel.cu:1541. Typically the list is just the sphere the
                 // tile itself lies on.
                 bool all_clear = false;
-                if (CULL && s_use_list && scount <= 4 && !fc.force_slow && !(fc.ablate & 128) &&
+                if (CULL && !MESH && s_use_list && scount <= 4 && !fc.force_slow && !(fc.ablate & 128) &&
                     (fc.n_planes | fc.n_cubes) == 0) {
                     bool clear = true;
                     for (int e = 0; e < scount; ++e) {
@@ -860,6 +934,24 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                             cur = nxt;
                             if (STATS == 1) { st_shadow += __popcll(__ballot(lit)); st_slots += 64; }
                             if (__all(shadowed)) break;
+                        }
+                    }
+                    // triangles, kernel.cu:1475-1497 (the reference tests them first; an
+                    // any-hit does not depend on the order)
+                    if (MESH && !__all(shadowed)) {
+                        const V3 inv{1.f / new_dir.x, 1.f / new_dir.y, 1.f / new_dir.z};
+                        for (int bj = 0; bj < fc.n_boxes; ++bj) {
+                            const RtBoxDev bx = fc.boxes[bj];
+                            const bool bh = !shadowed && box_intersect(bx, start, inv);
+                            if (__any(bh)) {
+                                for (int i = 0; i < bx.len; ++i) {
+                                    const RtTriDev *tp = fc.tris + fc.tri_idx[bx.start + i];
+                                    float t, u, v;
+                                    if (bh && !shadowed && tri_intersect(start, new_dir, tp->p0, tp->p1, tp->p2, t, u, v))
+                                        shadowed = true;
+                                }
+                                if (__all(shadowed)) break;
+                            }
                         }
                     }
                     // planes (kernel.cu:1511-1523) then cubes (:1524-1536), any-hit
@@ -1037,6 +1129,12 @@ extern "C" hipError_t rt_dev_prepare(void)
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
 #define RT_ATTR_TW(TW) RT_ATTR(TW, true, 0); RT_ATTR(TW, false, 0); RT_ATTR(TW, true, 1); RT_ATTR(TW, false, 1); RT_ATTR(TW, true, 2); RT_ATTR(TW, false, 2)
     RT_ATTR_TW(8);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)rt_trace_tiles<8, true, 0, true, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)rt_trace_tiles<8, false, 0, true, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     RT_ATTR_TW(16);
     RT_ATTR_TW(32);
     RT_ATTR_TW(64);
@@ -1049,6 +1147,7 @@ extern "C" hipError_t rt_dev_prepare(void)
 extern "C" hipError_t rt_dev_launch_trace(const RtFrameConsts *fc, const float4 *spheres, int tile_w,
                                           int cull, int stats, int table_in_lds, hipStream_t stream)
 {
+    if (fc->n_boxes > 0 && (tile_w != 8 || stats != 0)) return hipErrorNotSupported;   // mesh scenes: default tile only
     const int n_pad = (fc->n_spheres + 63) & ~63;
     const size_t lds_bytes = (size_t)((table_in_lds ? n_pad : 0) + RT_WAVES_PER_WG * RT_LIST_CAP) * sizeof(float4);
     const int band_h = fc->local_rows;
@@ -1062,6 +1161,17 @@ extern "C" hipError_t rt_dev_launch_trace(const RtFrameConsts *fc, const float4 
         if (pe != hipSuccess) return pe;
     }
 
+    if (fc->n_boxes > 0) {
+        if (cull && table_in_lds)
+            hipLaunchKernelGGL((rt_trace_tiles<8, true, 0, true, true>), grid, block, lds_bytes, stream, *fc, spheres);
+        else if (cull)
+            hipLaunchKernelGGL((rt_trace_tiles<8, true, 0, false, true>), grid, block, lds_bytes, stream, *fc, spheres);
+        else if (table_in_lds)
+            hipLaunchKernelGGL((rt_trace_tiles<8, false, 0, true, true>), grid, block, lds_bytes, stream, *fc, spheres);
+        else
+            hipLaunchKernelGGL((rt_trace_tiles<8, false, 0, false, true>), grid, block, lds_bytes, stream, *fc, spheres);
+        return hipGetLastError();
+    }
 #define RT_LAUNCH(TW, C, S)                                                                        \
     do {                                                                                           \
         if (table_in_lds)                                                                          \

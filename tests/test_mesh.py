@@ -1,0 +1,190 @@
+"""Triangle-mesh path: OBJ loader + flat BVH of the
+product against the oracle's restatement (CPU), Moller-Trumbore KATs, and
+bit-exact rendering on the GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import meshes
+
+OBJS = {
+    "uv_sphere_quads": meshes.uv_sphere_obj(),
+    "uv_sphere_tris": meshes.uv_sphere_obj(quads=False, n_lat=7, n_lon=9),
+    "box_bare_indices": meshes.box_obj_no_normals(),
+    "normals_only_quad": meshes.normals_only_obj(),
+    "with_blank_and_comment_lines": "# c\n\nv 0 0 0\nv 1 0 0\n\nv 0 1 0\r\nf 1 2 3\n",
+}
+
+
+def test_mesh_struct_layouts(rt, oracle):
+    assert C.sizeof(rt.Triangle) == 108 == C.sizeof(oracle.OTriangle)      # kernel.cu:1018-1020
+    assert C.sizeof(rt.BvhBox) == 40 and rt.BvhBox.length.offset == 32      # Bvhbox, kernel.cu:512-543
+    assert rt.Mesh.poly_count.offset == 16 and rt.Mesh.has_normals.offset == 28 and rt.Mesh.h_box.offset == 32
+
+
+@pytest.mark.parametrize("name", sorted(OBJS))
+def test_loader_and_bvh_match_oracle(name, rt, oracle):
+    txt = OBJS[name]
+    m = rt.mesh_from_obj_text(txt)
+    om = oracle.Mesh(txt)
+    mm = m.contents
+    assert (mm.poly_count, mm.bvhbox_count, bool(mm.has_normals)) == (om.poly_count, om.bvhbox_count, om.has_normals)
+    assert mm.bvhLayer_count == 10
+    tri = np.ctypeslib.as_array(C.cast(mm.d_tri_arr, C.POINTER(C.c_float)), shape=(mm.poly_count, 27))
+    assert np.array_equal(tri.view(np.uint32), om.triangles().view(np.uint32))
+    seen = []
+    for j, (b, org, idx) in enumerate(om.boxes()):
+        bx = mm.d_box[j]
+        c = bx.d_bvhbox.contents
+        assert [c.bounds[0].x, c.bounds[0].y, c.bounds[0].z, c.bounds[1].x, c.bounds[1].y, c.bounds[1].z] == b
+        assert [c.orgin.x, c.orgin.y, c.orgin.z] == org
+        assert [bx.d_indexes[i] for i in range(bx.length)] == idx
+        seen += idx
+    assert sorted(seen) == list(range(mm.poly_count))          # every triangle in exactly one leaf
+    rt.load_library().rt_mesh_free(m)
+
+
+def test_loader_quirks(rt):
+    """Quirks of the reference loader that are reproduced (kernel.cu:660-675, 700-712):
+    a quad's second half keeps the first half's face normal and repeats vt[2];
+    the a//c quad's second half repeats the first three vertex normals."""
+    txt = ("v 0 0 0\nv 1 0 0\nv 1 1 0.5\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+           "vn 0 0 1\nvn 0 0.6 0.8\nvn 0.6 0 0.8\nvn 1 0 0\nf 1/1/1 2/2/2 3/3/3 4/4/4\n")
+    mm = rt.mesh_from_obj_text(txt).contents
+    assert mm.poly_count == 2 and mm.has_normals == 1
+    t1, t2 = mm.d_tri_arr[0], mm.d_tri_arr[1]
+    assert (t2.points[1].x, t2.points[1].y, t2.points[1].z) == (1, 1, 0.5)      # 0,2,3
+    assert (t2.normal.x, t2.normal.y, t2.normal.z) == (t1.normal.x, t1.normal.y, t1.normal.z)
+    assert (t2.vt[1].u, t2.vt[1].v) == (1, 1) and (t2.vt[2].u, t2.vt[2].v) == (1, 1)   # vt[pvt[2]] twice
+    assert (t2.vecNormal[2].x) == 1.0                                           # vn[pvn[3]]
+    mm2 = rt.mesh_from_obj_text(meshes.normals_only_obj()).contents
+    q2 = mm2.d_tri_arr[1]
+    assert (q2.vecNormal[1].y, q2.vecNormal[2].x) == (np.float32(0.1), np.float32(0.1))   # vn[pvn[1]], vn[pvn[2]]
+    bare = rt.mesh_from_obj_text(meshes.box_obj_no_normals()).contents
+    assert bare.has_normals == 0
+    assert bare.d_tri_arr[0].vt[0].u == np.float32(0.666413)
+    lib = rt.load_library()
+    assert not lib.rt_mesh_from_obj_text(b"v 0 0 0\n")                     # no faces
+    assert not lib.rt_mesh_from_obj_text(b"v 0 0 0\nf 1 2 3\n")            # index out of range
+    assert not lib.rt_mesh_load_obj(b"/nonexistent.obj")
+
+
+def test_bvh_split_rule(rt):
+    """createBvhMesh (kernel.cu:752-937): leaves of <= 5 triangles are kept, larger
+    ones are cut at the middle of their bounds by the first vertex, the axis
+    advancing y, x, z after every cut."""
+    lines = []
+    for i in range(12):            # 12 small triangles stacked along y
+        y = float(i)
+        lines += ["v 0 %g 0" % y, "v 1 %g 0" % y, "v 0 %g 1" % (y + 0.25)]
+    lines += ["f %d %d %d" % (3 * i + 1, 3 * i + 2, 3 * i + 3) for i in range(12)]
+    mm = rt.mesh_from_obj_text("\n".join(lines) + "\n").contents
+    leaves = [[mm.d_box[j].d_indexes[i] for i in range(mm.d_box[j].length)] for j in range(mm.bvhbox_count)]
+    # pass 0: y-cut of [0, 11.25] at 5.625 -> 0..5 | 6..11 (axis -> x). pass 1: 0..5 cut along x: every
+    # first vertex has x = 0 <= 0.5, the other half is empty, the leaf survives (axis -> z); 6..11 cut
+    # along z: same (axis -> y). pass 2: 0..5 cut along y at (0 + 5.25)/2 -> 0,1,2 | 3,4,5 (axis -> x);
+    # 6..11 along x: survives (-> z). pass 3: 6..11 along z: survives (-> y). pass 4: y at (6 + 11.25)/2.
+    assert leaves == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 10, 11]]
+
+
+def test_moller_trumbore_kats(oracle):
+    lib = oracle.load()
+    tri = oracle.OTriangle()
+    for k, p in enumerate(((0, 0, 5), (1, 0, 5), (0, 1, 5))):
+        tri.points[k] = oracle.OVec3(*p)
+    t, u, v = C.c_float(), C.c_float(), C.c_float()
+
+    def hit(org, d):
+        r = oracle.ORay(oracle.OVec3(*org), oracle.OVec3(*d))
+        return lib.oracle_triangle_intersect(C.byref(tri), C.byref(r), C.byref(t), C.byref(u), C.byref(v))
+
+    assert hit((0.25, 0.25, 0), (0, 0, 1)) == 1 and (t.value, u.value, v.value) == (5.0, 0.25, 0.25)
+    assert hit((0.25, 0.25, 0), (0, 0, -1)) == 0                  # behind: t = -5 fails t > 1e-7
+    assert hit((0.75, 0.75, 0), (0, 0, 1)) == 0                   # u + v > 1
+    assert hit((-0.1, 0.2, 0), (0, 0, 1)) == 0                    # u < 0
+    assert hit((0.25, 0.25, 0), (1, 0, 0)) == 0                   # parallel: |a| < 1e-7
+    assert hit((0.25, 0.25, 10), (0, 0, -1)) == 1 and t.value == 5.0   # no back-face culling
+    assert hit((0.0, 0.0, 0), (0, 0, 1)) == 1 and (u.value, v.value) == (0.0, 0.0)   # on a vertex: inclusive
+
+
+# ------------------------------------------------------------------ GPU
+def _render_both(rt, inp, mesh, w, h, **kw):
+    import oracle_py
+    import torch
+    om = oracle_py.Mesh(mesh)
+    rgba, packed, cnt = oracle_py.render(inp.spheres, inp.n, inp.tex, inp.sky, inp.sky_box, inp.lights, inp.n_lights,
+                                         inp.cam, w, h, inp.aspect, nthreads=16, mesh=om.handle,
+                                         cubes=getattr(inp, "cubes", None), n_cubes=getattr(inp, "n_cubes", 0),
+                                         planes=getattr(inp, "planes", None), n_planes=getattr(inp, "n_planes", 0))
+    sc = inp.scene()
+    if getattr(inp, "n_planes", 0):
+        sc.set_planes(inp.planes, inp.n_planes)
+    if getattr(inp, "n_cubes", 0):
+        sc.set_cubes(inp.cubes, inp.n_cubes)
+    pm = rt.mesh_from_obj_text(mesh)
+    sc.set_mesh(pm)
+    for cull in (True, False):
+        out = sc.render(w, h, cull=cull, cam=inp.cam)
+        torch.cuda.synchronize()
+        got = out["rgba"].cpu().numpy()
+        bad = int((got.view(np.uint32) != rgba.view(np.uint32)).any(axis=2).sum())
+        assert bad == 0, (cull, bad)
+        assert np.array_equal(out["packed"].cpu().numpy().view(np.uint32), packed)
+    return cnt
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["uv_sphere_quads", "uv_sphere_tris", "box_bare_indices", "normals_only_quad"])
+def test_mesh_render_matches_oracle(name, rt, gpu):
+    from scenes import Inputs
+    inp = Inputs(rt, 64)
+    cnt = _render_both(rt, inp, OBJS[name], 160, 90)
+    assert cnt["hit_pixels"] >= 3187         # at least the 64 spheres alone
+
+
+@pytest.mark.gpu
+def test_mesh_with_every_primitive_kind(rt, gpu):
+    from scenes import mixed_scene
+    inp = mixed_scene(rt)
+    _render_both(rt, inp, meshes.uv_sphere_obj(cx=5.0, cy=3.0, cz=6.0, r=1.2, n_lat=8, n_lon=12), 128, 80)
+
+
+@pytest.mark.gpu
+def test_mesh_only_scene_and_shim(rt, gpu):
+    """No spheres, only the mesh; then the same through rt_launch_raytrace with
+    objs->mesh1 pointing at the reference-layout mesh."""
+    import oracle_py
+    import torch
+    from scenes import Inputs
+    from test_gpu_parity import _managed_sprite
+    lib = rt.load_library()
+    inp = Inputs(rt, 0)
+    txt = meshes.uv_sphere_obj(cx=4.0, cy=1.5, cz=6.0, r=2.0, n_lat=12, n_lon=20)
+    _render_both(rt, inp, txt, 128, 80)
+    w, h = 128, 80
+    om = oracle_py.Mesh(txt)
+    _, want, _ = oracle_py.render(inp.spheres, 0, inp.tex, inp.sky, inp.sky_box, inp.lights, 3, inp.cam, w, h,
+                                  inp.aspect, nthreads=16, mesh=om.handle)
+    obj = C.cast(lib.rt_managed_alloc(C.sizeof(rt.Object)), C.POINTER(rt.Object))
+    C.memset(obj, 0, C.sizeof(rt.Object))
+    obj.contents.texture = _managed_sprite(rt, inp.tex)
+    obj.contents.mesh1 = rt.mesh_from_obj_text(txt)
+    sky = C.cast(lib.rt_managed_alloc(C.sizeof(rt.Skybox)), C.POINTER(rt.Skybox))
+    box = C.cast(lib.rt_managed_alloc(32), C.POINTER(rt.Sphere))
+    C.memmove(box, C.byref(inp.sky_box), 32)
+    sky.contents.box = box
+    sky.contents.skyboxTex = _managed_sprite(rt, inp.sky)
+    pixels = lib.rt_managed_alloc(4 * w * h)
+    assert lib.rt_launch_raytrace(pixels, w, h, inp.aspect, obj, inp.lights, 3, inp.cam, sky, None) == 0, lib.rt_last_error()
+    torch.cuda.synchronize()
+    got = np.ctypeslib.as_array(C.cast(pixels, C.POINTER(C.c_uint32)), shape=(h, w)).copy()
+    assert np.array_equal(got, want)
+    obj.contents.mesh1 = None                                   # and without it again (cache must notice)
+    assert lib.rt_launch_raytrace(pixels, w, h, inp.aspect, obj, inp.lights, 3, inp.cam, sky, None) == 0
+    torch.cuda.synchronize()
+    got0 = np.ctypeslib.as_array(C.cast(pixels, C.POINTER(C.c_uint32)), shape=(h, w)).copy()
+    _, want0, _ = oracle_py.render(inp.spheres, 0, inp.tex, inp.sky, inp.sky_box, inp.lights, 3, inp.cam, w, h,
+                                   inp.aspect, nthreads=16)
+    assert np.array_equal(got0, want0)
