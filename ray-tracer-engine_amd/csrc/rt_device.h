@@ -22,6 +22,7 @@
                                // that add 0.6 GB of scratch writes per frame.
 #endif
 #define RT_WAVES_PER_WG 4
+#define RT_BOX_CAP 128          // leaf-box list capacity per wave (ints in LDS, mesh scenes only)
 #ifndef RT_TABLE_LDS_MAX
 #define RT_TABLE_LDS_MAX 1024   // sphere tables up to this size are staged in LDS (16 KiB); measured at
                                 // 3840x2160: N=1024 LDS 1.48 ms vs global 1.50 ms, N=4096 LDS 4.49 vs global 2.64
@@ -108,6 +109,7 @@ struct RtFrameConsts {
     const RtTriDev *tris;
     const RtBoxDev *boxes;
     const int *tri_idx;
+    const float *box_spheres;   // float4 per leaf: bounding sphere {cx,cy,cz,r^2} for beam culling
     int n_boxes, mesh_has_normals;
 
     // outputs

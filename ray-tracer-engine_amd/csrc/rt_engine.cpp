@@ -126,6 +126,7 @@ struct rt_scene {
     RtTriDev *d_tris = nullptr;
     RtBoxDev *d_boxes = nullptr;
     int *d_tri_idx = nullptr;
+    float *d_box_spheres = nullptr;
     int n_boxes = 0, n_tris = 0, mesh_has_normals = 0;
 };
 
@@ -165,6 +166,7 @@ extern "C" void rt_scene_destroy(rt_scene *s)
     if (s->d_tris) (void)hipFree(s->d_tris);
     if (s->d_boxes) (void)hipFree(s->d_boxes);
     if (s->d_tri_idx) (void)hipFree(s->d_tri_idx);
+    if (s->d_box_spheres) (void)hipFree(s->d_box_spheres);
     delete s;
 }
 
@@ -274,7 +276,8 @@ extern "C" int rt_scene_set_mesh(rt_scene *s, const rt_mesh *mesh)
     if (s->d_tris) RT_HIP(hipFree(s->d_tris));
     if (s->d_boxes) RT_HIP(hipFree(s->d_boxes));
     if (s->d_tri_idx) RT_HIP(hipFree(s->d_tri_idx));
-    s->d_tris = nullptr; s->d_boxes = nullptr; s->d_tri_idx = nullptr;
+    if (s->d_box_spheres) RT_HIP(hipFree(s->d_box_spheres));
+    s->d_tris = nullptr; s->d_boxes = nullptr; s->d_tri_idx = nullptr; s->d_box_spheres = nullptr;
     s->n_boxes = s->n_tris = 0;
     if (!mesh || mesh->bvhbox_count == 0) return RT_OK;
     if (mesh->poly_count <= 0 || mesh->bvhbox_count < 0 || !mesh->d_tri_arr || !mesh->d_box) {
@@ -293,6 +296,7 @@ extern "C" int rt_scene_set_mesh(rt_scene *s, const rt_mesh *mesh)
         memcpy(d.vt, t.vt, 24);
     }
     std::vector<RtBoxDev> boxes((size_t)mesh->bvhbox_count);
+    std::vector<float> bsph((size_t)mesh->bvhbox_count * 4);   // bounding sphere of each leaf (for beam culling)
     std::vector<int> idx;
     for (int j = 0; j < mesh->bvhbox_count; ++j) {
         const rt_bvhbox &b = mesh->d_box[j];
@@ -304,6 +308,14 @@ extern "C" int rt_scene_set_mesh(rt_scene *s, const rt_mesh *mesh)
         RtBoxDev &d = boxes[j];
         d.lo[0] = c->bounds[0].x; d.lo[1] = c->bounds[0].y; d.lo[2] = c->bounds[0].z;
         d.hi[0] = c->bounds[1].x; d.hi[1] = c->bounds[1].y; d.hi[2] = c->bounds[1].z;
+        {
+            const double cx = 0.5 * ((double)d.lo[0] + d.hi[0]), cy = 0.5 * ((double)d.lo[1] + d.hi[1]),
+                         cz = 0.5 * ((double)d.lo[2] + d.hi[2]);
+            const double hx = 0.5 * std::fabs((double)d.hi[0] - d.lo[0]), hy = 0.5 * std::fabs((double)d.hi[1] - d.lo[1]),
+                         hz = 0.5 * std::fabs((double)d.hi[2] - d.lo[2]);
+            bsph[4 * j + 0] = (float)cx; bsph[4 * j + 1] = (float)cy; bsph[4 * j + 2] = (float)cz;
+            bsph[4 * j + 3] = (float)((hx * hx + hy * hy + hz * hz) * 1.001 + 1e-6);   // radius^2, rounded up
+        }
         d.start = (int)idx.size();
         d.len = b.length;
         for (int i = 0; i < b.length; ++i) {
@@ -317,6 +329,8 @@ extern "C" int rt_scene_set_mesh(rt_scene *s, const rt_mesh *mesh)
     RT_HIP(hipMalloc((void **)&s->d_tris, sizeof(RtTriDev) * tris.size()));
     RT_HIP(hipMalloc((void **)&s->d_boxes, sizeof(RtBoxDev) * boxes.size()));
     RT_HIP(hipMalloc((void **)&s->d_tri_idx, sizeof(int) * (idx.size() ? idx.size() : 1)));
+    RT_HIP(hipMalloc((void **)&s->d_box_spheres, sizeof(float) * bsph.size()));
+    RT_HIP(hipMemcpy(s->d_box_spheres, bsph.data(), sizeof(float) * bsph.size(), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(s->d_tris, tris.data(), sizeof(RtTriDev) * tris.size(), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(s->d_boxes, boxes.data(), sizeof(RtBoxDev) * boxes.size(), hipMemcpyHostToDevice));
     if (!idx.empty()) RT_HIP(hipMemcpy(s->d_tri_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
@@ -555,6 +569,7 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
     fc->tris = s->d_tris;
     fc->boxes = s->d_boxes;
     fc->tri_idx = s->d_tri_idx;
+    fc->box_spheres = s->d_box_spheres;
     fc->n_boxes = s->n_boxes;
     fc->mesh_has_normals = s->mesh_has_normals;
     fc->rgba = o.rgba;

@@ -359,6 +359,26 @@ __device__ __forceinline__ int build_list(const float4 *tab, const float4 *__res
 }
 
 
+// Leaf boxes of the mesh that the beam can touch, as indices in leaf order. A ray
+// tests a leaf's triangles only after passing the leaf's slab test, i.e. only if
+// it crosses the box, hence its bounding sphere: the sphere test with the usual
+// padding is conservative. Order is kept (first triangle wins ties, kernel.cu:1309).
+__device__ __forceinline__ int build_box_list(const float4 *__restrict__ bsph, int nb, int *list, const Beam &b, int lane)
+{
+    int count = 0;
+    for (int base = 0; base < nb; base += 64) {
+        const int i = base + lane;
+        const float4 s = bsph[i < nb ? i : nb - 1];
+        const bool keep = (i < nb) && beam_keeps(b, s);
+        const unsigned long long m = __ballot(keep);
+        const int pos = count + lane_prefix(m);
+        if (keep && pos < RT_BOX_CAP) list[pos] = i;
+        count += __popcll(m);
+    }
+    wave_lds_sync();
+    return count;
+}
+
 // ---------------------------------------------------------------------------
 // castLightRay's sample construction, kernel.cu:1438-1468 (exact)
 // ---------------------------------------------------------------------------
@@ -496,6 +516,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
         __syncthreads();
     }
     float4 *mylist = lds + (TABLDS ? n_pad : 0) + wave * RT_LIST_CAP;
+    int *myboxes = reinterpret_cast<int *>(lds + (TABLDS ? n_pad : 0) + RT_WAVES_PER_WG * RT_LIST_CAP) + wave * RT_BOX_CAP;
 
     const int tile_x = (blockIdx.x * WGX + (wave % WGX)) * TW;
     // local row -> global row: a contiguous band, or row blocks dealt round-robin
@@ -554,6 +575,8 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
         // ================= castRay, sphere branch =================
         bool p_use_list = false;   // false: walk the whole table
         int pcount = n;
+        bool pb_use_list = false;  // leaf boxes of the mesh: false = all of them
+        int pbcount = MESH ? fc.n_boxes : 0;
         if (CULL) {
             // cone around the tile's mean direction, apex at the (shared) origin
             float sx = wave_sum(D.x), sy = wave_sum(D.y), sz = wave_sum(D.z);
@@ -580,6 +603,13 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                     st_overflow += 1;
                 }
                 if (STATS == 1) st_entries += (unsigned long long)(c <= RT_LIST_CAP ? c : n);
+                if (MESH) {
+                    const int cb = build_box_list(reinterpret_cast<const float4 *>(fc.box_spheres), fc.n_boxes, myboxes, b, lane);
+                    if (cb <= RT_BOX_CAP) {
+                        pb_use_list = true;
+                        pbcount = cb;
+                    }
+                }
             }
         }
 
@@ -593,7 +623,8 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
             // triangles through the flat list of leaf boxes, kernel.cu:1293-1328 (before
             // the spheres, as there): a lane tests a leaf's triangles iff its ray hits the box
             const V3 inv{1.f / D.x, 1.f / D.y, 1.f / D.z};
-            for (int j = 0; j < fc.n_boxes; ++j) {
+            for (int jj = 0; jj < pbcount; ++jj) {
+                const int j = pb_use_list ? myboxes[jj] : jj;
                 const RtBoxDev bx = fc.boxes[j];
                 const bool bh = box_intersect(bx, O, inv);
                 if (__any(bh)) {
@@ -793,6 +824,8 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                 // ---------- conservative beam for this light's 10 x 64 rays ----------
                 bool s_use_list = false;
                 int scount = n;
+                bool sb_use_list = false;
+                int sbcount = MESH ? fc.n_boxes : 0;
                 float beam_k = 0.f;   // slope of the light's beam (valid when s_use_list)
                 if (CULL) {
                     bool ok = true;
@@ -870,6 +903,13 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                             wave_lds_sync();
                             continue;
                         }
+                        if (MESH) {
+                            const int cbx = build_box_list(reinterpret_cast<const float4 *>(fc.box_spheres), fc.n_boxes, myboxes, b, lane);
+                            if (cbx <= RT_BOX_CAP) {
+                                sb_use_list = true;
+                                sbcount = cbx;
+                            }
+                        }
                         if (c <= RT_LIST_CAP) {
                             s_use_list = true;
                             scount = c;
@@ -898,8 +938,8 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                 // needed for kernel.cu:1541. Typically the list is just the sphere the
                 // tile itself lies on.
                 bool all_clear = false;
-                if (CULL && !MESH && s_use_list && scount <= 4 && !fc.force_slow && !(fc.ablate & 128) &&
-                    (fc.n_planes | fc.n_cubes) == 0) {
+                if (CULL && (!MESH || (sb_use_list && sbcount == 0)) && s_use_list && scount <= 4 && !fc.force_slow &&
+                    !(fc.ablate & 128) && (fc.n_planes | fc.n_cubes) == 0) {
                     bool clear = true;
                     for (int e = 0; e < scount; ++e) {
                         const float4 sp = mylist[e];
@@ -940,7 +980,8 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                     // any-hit does not depend on the order)
                     if (MESH && !__all(shadowed)) {
                         const V3 inv{1.f / new_dir.x, 1.f / new_dir.y, 1.f / new_dir.z};
-                        for (int bj = 0; bj < fc.n_boxes; ++bj) {
+                        for (int bjj = 0; bjj < sbcount; ++bjj) {
+                            const int bj = sb_use_list ? myboxes[bjj] : bjj;
                             const RtBoxDev bx = fc.boxes[bj];
                             const bool bh = !shadowed && box_intersect(bx, start, inv);
                             if (__any(bh)) {
@@ -1149,7 +1190,8 @@ extern "C" hipError_t rt_dev_launch_trace(const RtFrameConsts *fc, const float4 
 {
     if (fc->n_boxes > 0 && (tile_w != 8 || stats != 0)) return hipErrorNotSupported;   // mesh scenes: default tile only
     const int n_pad = (fc->n_spheres + 63) & ~63;
-    const size_t lds_bytes = (size_t)((table_in_lds ? n_pad : 0) + RT_WAVES_PER_WG * RT_LIST_CAP) * sizeof(float4);
+    const size_t lds_bytes = (size_t)((table_in_lds ? n_pad : 0) + RT_WAVES_PER_WG * RT_LIST_CAP) * sizeof(float4) +
+                             (fc->n_boxes > 0 ? (size_t)RT_WAVES_PER_WG * RT_BOX_CAP * sizeof(int) : 0);
     const int band_h = fc->local_rows;
     const int th = 64 / tile_w;
     const int wgx = (tile_w <= 16) ? 2 : 1;
