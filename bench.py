@@ -160,9 +160,9 @@ def main():
     # Two packed buffers so that frame i's gather overlaps frame i+1's kernel.
     rgba = torch.empty((rows, w, 4), dtype=torch.float32, device="cuda")
     packed2 = [torch.zeros((max_rows, w), dtype=torch.int32, device="cuda") for _ in range(2)]
-    gathered2 = [[torch.empty((max_rows, w), dtype=torch.int32, device=coll_dev) for _ in range(world)]
-                 for _ in range(2)] if (world > 1 and rank == 0) else [None, None]
-    frame = torch.empty((h, w), dtype=torch.int32, device=coll_dev) if (world > 1 and rank == 0) else None
+    roots = [rd.InterleavedGather(h, w, world, coll_dev, BLOCK) for _ in range(2)] if (world > 1 and rank == 0) else None
+    gathered2 = [roots[0].views, roots[1].views] if roots else [None, None]
+    frame = None
     stream = torch.cuda.current_stream()
     fds = [scene.frame_desc(w, h, pixels=p.data_ptr(), rgba=rgba.data_ptr(), y0=y0, y1=y1, spp=args.spp,
                             cull=not args.no_cull, tile=args.tile, interleave=interleave) for p in packed2]
@@ -177,7 +177,8 @@ def main():
             pending[b].wait()
             pending[b] = None
             if rank == 0:
-                rd.assemble_interleaved(gathered2[b], h, BLOCK, out=frame)
+                nonlocal frame
+                frame = roots[b].assemble()       # one index_select puts every row in place
 
     def step(k, i=None):
         b = k & 1

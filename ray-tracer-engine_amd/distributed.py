@@ -68,3 +68,25 @@ def assemble_interleaved(gathered, height: int, block: int = 16, out=None) -> to
         idx = torch.as_tensor(interleaved_rows(height, r, world, block), device=g.device)
         out.index_copy_(0, idx, g[: idx.numel()])
     return out
+
+
+class InterleavedGather:
+    """Root-side buffers for the interleaved split: one contiguous receive buffer
+    whose per-rank slices are the gather list, and a row permutation so that the
+    whole frame is put in place by ONE index_select kernel per frame."""
+
+    def __init__(self, height: int, width: int, world: int, device, block: int = 16, dtype=torch.int32):
+        self.height, self.world, self.block = height, world, block
+        self.max_rows = max_interleaved_rows(height, world, block)
+        self.recv = torch.empty((world, self.max_rows, width), dtype=dtype, device=device)
+        self.views = [self.recv[r] for r in range(world)]
+        src = torch.empty(height, dtype=torch.int64)
+        for r in range(world):
+            rows = interleaved_rows(height, r, world, block)
+            src[torch.as_tensor(rows)] = r * self.max_rows + torch.arange(len(rows))
+        self.src_rows = src.to(device)            # frame row y comes from recv.view(-1, W)[src_rows[y]]
+        self.frame = torch.empty((height, width), dtype=dtype, device=device)
+
+    def assemble(self) -> torch.Tensor:
+        torch.index_select(self.recv.view(self.world * self.max_rows, -1), 0, self.src_rows, out=self.frame)
+        return self.frame

@@ -63,9 +63,13 @@ def _worker_interleaved(rank, world, port, w, h, out_path):
     # stand-in band content: every pixel encodes its GLOBAL row and column
     gy = torch.tensor(rows, dtype=torch.int32).unsqueeze(1)
     band[: len(rows)] = gy * 65536 + torch.arange(w, dtype=torch.int32).unsqueeze(0)
-    got = rd.gather_bands(band, dst=0)
+    root = rd.InterleavedGather(h, w, world, "cpu") if rank == 0 else None
+    got = rd.gather_bands(band, dst=0, out=root.views if root else None)
     if rank == 0:
-        np.save(out_path, rd.assemble_interleaved(got, h, 16).numpy())
+        a = rd.assemble_interleaved(got, h, 16)
+        b = root.assemble()                       # the one-kernel variant bench.py uses
+        assert torch.equal(a, b)
+        np.save(out_path, b.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
