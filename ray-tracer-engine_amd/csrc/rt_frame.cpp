@@ -118,7 +118,18 @@ void onStart()
     memset(objs, 0, sizeof *objs);
     objs->depth = 3;
     objs->sphere_count = cfg_sphere_count;
-    // loadMesh: mesh/cube/plane stay empty (out of scope), spheres from the rand() replay
+    // loadMesh (kernel.cu:1181-1207): `mesh1 = new mesh(file)` -- here only when RT_MESH_OBJ names an
+    // OBJ file (the reference's skull2.obj is not in its repository); cubes/planes stay empty as shipped
+    if (const char *obj_path = getenv("RT_MESH_OBJ")) {
+        if (*obj_path) {
+            objs->mesh1 = rt_mesh_load_obj(obj_path);
+            if (!objs->mesh1) {
+                fprintf(stderr, "onStart: %s\n", rt_last_error());
+                rt_check(1, "mesh(file)", __FILE__, __LINE__);
+            }
+        }
+    }
+    // spheres from the rand() replay
     objs->s1 = (rt_sphere *)calloc((size_t)(cfg_sphere_count > 0 ? cfg_sphere_count : 1), sizeof(rt_sphere));
     rt_generate_spheres(objs->s1, cfg_sphere_count, cfg_seed);
     objs->texture = (rt_sprite *)new sprite(env_or("RT_OBJECT_TEXTURE", "synthetic:object"));

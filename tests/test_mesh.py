@@ -109,6 +109,17 @@ def test_moller_trumbore_kats(oracle):
     assert hit((0.0, 0.0, 0), (0, 0, 1)) == 1 and (u.value, v.value) == (0.0, 0.0)   # on a vertex: inclusive
 
 
+def test_mesh_golden(rt, oracle):
+    from scenes import Inputs
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mesh_160x90.npz"))
+    inp = Inputs(rt, 64)
+    om = oracle.Mesh(meshes.uv_sphere_obj())
+    rgba, packed, cnt = oracle.render(inp.spheres, inp.n, inp.tex, inp.sky, inp.sky_box, inp.lights, 3, inp.cam,
+                                      160, 90, inp.aspect, nthreads=8, mesh=om.handle)
+    assert np.array_equal(rgba[..., :3].view(np.uint32), g["rgb"].view(np.uint32)) and np.array_equal(packed, g["packed"])
+    assert cnt["hit_pixels"] == int(g["counters"][2]) == 7257
+
+
 # ------------------------------------------------------------------ GPU
 def _render_both(rt, inp, mesh, w, h, **kw):
     import oracle_py
@@ -188,3 +199,31 @@ def test_mesh_only_scene_and_shim(rt, gpu):
     _, want0, _ = oracle_py.render(inp.spheres, 0, inp.tex, inp.sky, inp.sky_box, inp.lights, 3, inp.cam, w, h,
                                    inp.aspect, nthreads=16)
     assert np.array_equal(got0, want0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_mesh_fuzz_triangle_soup(rt, gpu, seed):
+    """Random triangle soups (degenerate and tiny triangles included) among random
+    spheres, random camera: culled == brute force == oracle."""
+    from test_gpu_scenarios import Scn, _cam
+    rng = np.random.default_rng(500 + seed)
+    nt = int(rng.integers(8, 120))
+    lines = []
+    for _ in range(nt):
+        c = rng.uniform(0, 10, 3)
+        for _ in range(3):
+            p = c + rng.normal(size=3) * float(rng.choice([0.05, 0.6, 2.0]))
+            lines.append("v %.5f %.5f %.5f" % tuple(p))
+    if seed % 2:
+        lines += ["vn %.4f %.4f %.4f" % tuple(rng.normal(size=3)) for _ in range(7)]
+        lines += ["f %d//%d %d//%d %d//%d" % (3 * i + 1, i % 7 + 1, 3 * i + 2, (i + 1) % 7 + 1, 3 * i + 3, (i + 2) % 7 + 1)
+                  for i in range(nt)]
+    else:
+        lines += ["f %d %d %d" % (3 * i + 1, 3 * i + 2, 3 * i + 3) for i in range(nt)]
+    txt = "\n".join(lines) + "\n"
+    sph = [tuple(rng.uniform(0, 10, 3)) + (rng.uniform(0.2, 0.9),) for _ in range(int(rng.integers(0, 60)))]
+    sc = Scn(rt, sph, cam=_cam(rt, tuple(rng.uniform(-2, 12, 3)), float(rng.uniform(0, 360)), float(rng.uniform(-40, 40))))
+    inp = sc
+    inp.scene_obj = None
+    _render_both(rt, inp, txt, 96, 64)

@@ -42,6 +42,16 @@ def main():
                         counters=np.array([cnt["primary_tests"], cnt["shadow_tests"], cnt["hit_pixels"],
                                            cnt["unshadowed"]], dtype=np.uint64))
     print("mixed_160x96", cnt)
+    # triangle mesh (uv sphere, quads + triangles, vn + vt) among 64 spheres
+    import meshes
+    inp = Inputs(rt, 64)
+    om = oracle_py.Mesh(meshes.uv_sphere_obj())
+    rgba, packed, cnt = oracle_py.render(inp.spheres, inp.n, inp.tex, inp.sky, inp.sky_box, inp.lights, 3, inp.cam,
+                                         160, 90, inp.aspect, nthreads=8, mesh=om.handle)
+    np.savez_compressed(os.path.join(out_dir, "mesh_160x90.npz"), rgb=rgba[..., :3].copy(), packed=packed,
+                        counters=np.array([cnt["primary_tests"], cnt["shadow_tests"], cnt["hit_pixels"],
+                                           cnt["unshadowed"]], dtype=np.uint64))
+    print("mesh_160x90", cnt)
 
 
 if __name__ == "__main__":
