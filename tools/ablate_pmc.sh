@@ -10,7 +10,7 @@ a=sys.argv[1]
 f=glob.glob(f'/tmp/ab_{a}/*/*counter_collection.csv')[0]
 agg=collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    if 'rt_trace_tiles<8, true, 0, true>' in r['Kernel_Name']:
+    if 'rt_trace_tiles<8, true, 0, true' in r['Kernel_Name']:
         agg[r['Counter_Name']].append(float(r['Counter_Value']))
 m={k:sum(v)/len(v) for k,v in agg.items()}
 w=129600
