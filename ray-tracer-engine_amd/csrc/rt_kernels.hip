@@ -852,21 +852,32 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                         const float re = __builtin_amdgcn_rsqf(ex * ex + ey * ey + ez * ez);
                         const float dte = (toL.x * ex + toL.y * ey + toL.z * ez) * re;
                         const float angle = __cosf(2.f * dte);
+                        // A sample direction is w_j = l.pos - r_j with r_j = x_j R0 + y_j R1 + z_j R2
+                        // (rows of the matrix) and |(x,y,z)| = 1. Its deviation from u = l.pos/|l.pos|:
+                        // sin = |w x u| / |w| = |r x u| / |w| (l.pos x u = 0), with
+                        // r x u = x (R0 x u) + y (R1 x u) + z (R2 x u) and |w| >= |l.pos| - ||M||_F.
+                        const float a0x = m01 * b.uz - m02 * b.uy, a0y = m02 * b.ux - m00 * b.uz, a0z = m00 * b.uy - m01 * b.ux;
+                        const float a1x = m11 * b.uz - m12 * b.uy, a1y = m12 * b.ux - m10 * b.uz, a1z = m10 * b.uy - m11 * b.ux;
+                        const float a2x = m21 * b.uz - m22 * b.uy, a2y = m22 * b.ux - m20 * b.uz, a2z = m20 * b.uy - m21 * b.ux;
+                        const float frob2 = m00 * m00 + m01 * m01 + m02 * m02 + m10 * m10 + m11 * m11 + m12 * m12 +
+                                            m20 * m20 + m21 * m21 + m22 * m22;
+                        const float den = L.pos_len - __builtin_amdgcn_sqrtf(frob2) * 1.001f;
+                        float kmax2 = 0.f;
 #pragma unroll 1   // rolled: the unrolled form keeps 30 table values live in VGPRs
                         for (int j = 0; j < RT_SHADOW_SAMPLES; ++j) {
-                            const float z = fc.jf[j] * (1.f - angle) + angle;
-                            const float sq = __builtin_amdgcn_sqrtf(__builtin_fmaxf(1.f - z * z, 0.f));
+                            const float z = __builtin_fmaf(fc.jf[j], 1.f - angle, angle);
+                            const float sq = __builtin_amdgcn_sqrtf(__builtin_fmaxf(__builtin_fmaf(-z, z, 1.f), 0.f));
                             const float x = sq * fc.jcos[j], y = sq * fc.jsin[j];
-                            const float wx = lpos.x - (x * m00 + y * m10 + z * m20);
-                            const float wy = lpos.y - (x * m01 + y * m11 + z * m21);
-                            const float wz = lpos.z - (x * m02 + y * m12 + z * m22);
-                            const float kx = wy * b.uz - wz * b.uy, ky = wz * b.ux - wx * b.uz,
-                                        kz = wx * b.uy - wy * b.ux;
-                            const float s2 = (kx * kx + ky * ky + kz * kz) *
-                                             __builtin_amdgcn_rcpf(wx * wx + wy * wy + wz * wz);
+                            const float kx = __builtin_fmaf(x, a0x, __builtin_fmaf(y, a1x, z * a2x));
+                            const float ky = __builtin_fmaf(x, a0y, __builtin_fmaf(y, a1y, z * a2y));
+                            const float kz = __builtin_fmaf(x, a0z, __builtin_fmaf(y, a1z, z * a2z));
+                            const float k2 = __builtin_fmaf(kx, kx, __builtin_fmaf(ky, ky, kz * kz));
                             // not fmaxf: a NaN must poison the bound so that culling is skipped
-                            smax2 = (s2 > smax2 || s2 != s2) ? s2 : smax2;
+                            kmax2 = (k2 > kmax2 || k2 != k2) ? k2 : kmax2;
                         }
+                        // a light closer to the origin than the matrix can reach has no usable bound
+                        const float rden = __builtin_amdgcn_rcpf(den);
+                        smax2 = (den > 0.05f * L.pos_len) ? kmax2 * rden * rden * 1.0001f : __builtin_nanf("");
                     }
                     if (!lit) smax2 = 0.f;
                     const bool lane_bad = lit && !(smax2 < 0.25f);
