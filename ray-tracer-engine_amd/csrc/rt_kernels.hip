@@ -797,10 +797,15 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                 const RtLightDev L = fc.lights[li];
                 const V3 lpos{L.px, L.py, L.pz};
 
-                // toL = normalise(l.pos - start), kernel.cu:1438 (exact; the beam below
-                // is derived from it with fast math and padded)
+                // toL = normalise(l.pos - start), kernel.cu:1438 -- here only to ~1e-6 (fast
+                // reciprocal square root): it feeds the facing test and the beam bound, both of
+                // which carry margins; the exact value is formed by ShadowChain::begin when the
+                // samples are actually constructed.
                 V3 toL{lpos.x - start.x, lpos.y - start.y, lpos.z - start.z};
-                normalise_inplace(toL);
+                {
+                    const float inv = __builtin_amdgcn_rsqf(__builtin_fmaf(toL.x, toL.x, __builtin_fmaf(toL.y, toL.y, toL.z * toL.z)));
+                    toL.x *= inv; toL.y *= inv; toL.z *= inv;
+                }
 
                 // A surface that faces away from the light gets b *= 0 at kernel.cu:1542
                 // whatever its ten shadow samples say, and fr + (0*l.r)*r leaves fr
