@@ -315,3 +315,24 @@ def test_fuzz_random_scenes(rt, gpu, seed):
             a = rng.uniform(0, ext, 3)
             cubes.append(tuple(a) + tuple(a + rng.uniform(0.1, 2.0, 3)))
     Scn(rt, sph, lights=lights, cam=cam, tex=tex, planes=planes, cubes=cubes).check(64, 48, tiles=(8,))
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_fuzz_occluder_shortcuts(rt, gpu, seed):
+    """Scenes built to sit on the decision boundaries of the beam-level shortcuts:
+    big spheres that just cover / just fail to cover a tile's shadow beam, lights at
+    many distances, dense and sparse layers. Culled == brute force == oracle."""
+    rng = np.random.default_rng(7000 + seed)
+    n_small = int(rng.integers(20, 150))
+    sph = [tuple(rng.uniform(0, 10, 3)) + (float(rng.uniform(0.1, 0.7)),) for _ in range(n_small)]
+    for _ in range(int(rng.integers(1, 6))):          # large occluders (effective radius r^2 up to ~3)
+        sph.append(tuple(rng.uniform(-2, 12, 3)) + (float(rng.uniform(0.9, 1.7)),))
+    rng.shuffle(sph)
+    lights = []
+    for _ in range(3):
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        lights.append((tuple(d * float(rng.choice([6.0, 15.0, 40.0, 200.0]))), float(rng.uniform(1, 30)),
+                       *[float(v) for v in rng.uniform(0.2, 1.0, 3)]))
+    cam = _cam(rt, tuple(rng.uniform(0, 10, 3) + np.array([0, 2, 6])), float(rng.uniform(150, 210)), float(rng.uniform(-35, 5)))
+    Scn(rt, sph, lights=lights, cam=cam).check(96, 64, tiles=(8, 16))
