@@ -112,6 +112,15 @@ struct RtFrameConsts {
     const float *box_spheres;   // float4 per leaf: bounding sphere {cx,cy,cz,r^2} for beam culling
     int n_boxes, mesh_has_normals;
 
+    // the sphere table once more in Morton order of the centres, cut into blocks of 64
+    // with a bounding sphere each: culling first tests the blocks, then only the spheres
+    // of the blocks a beam can touch. orig_idx[i] is the list position of sorted[i]
+    // (primary hits must be examined in list order: first index wins ties).
+    const float *sorted;       // float4 per sphere, n_pad entries
+    const float *blocks;       // float4 per block: centre and radius (already padded for its members)
+    const int *orig_idx;
+    int n_blocks, pad_blocks_;
+
     // outputs
     float *rgba;                // float4 per pixel, band-local, may be null
     uint32_t *packed;           // 0x00RRGGBB per pixel, band-local, may be null

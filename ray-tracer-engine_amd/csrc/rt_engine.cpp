@@ -15,7 +15,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "../../include/rt_engine.h"
@@ -105,8 +107,10 @@ extern "C" void rt_managed_free(void *ptr)
 // device-resident scene
 // ---------------------------------------------------------------------------
 struct rt_scene {
-    float4 *d_spheres = nullptr;
+    float4 *d_spheres = nullptr;     // [n] list order | [n_pad] Morton order | [n_blocks] block bounds | [n_pad] ints
     int n_spheres = 0, cap_spheres = 0;
+    int n_blocks = 0;
+    std::vector<float4> h_prev;      // what was uploaded last (skip identical re-mirrors)
     float4 *h_stage = nullptr;   // pinned staging for asynchronous re-uploads
     int cap_stage = 0;
     hipEvent_t stage_done = nullptr;   // the last upload out of h_stage
@@ -178,6 +182,67 @@ static void pack_spheres(const rt_sphere *src, int n, float4 *dst)
         dst[i] = make_float4(src[i].orgin.x, src[i].orgin.y, src[i].orgin.z, src[i].radius * src[i].radius);
 }
 
+// Morton order of the centres (10 bits per axis over the scene's bounds), blocks of
+// 64 consecutive spheres, and for each block a sphere that contains every member
+// (centre = mean of the members' centres, radius = max |c_i - centre| + R_i, rounded
+// up). Spheres with non-finite data make their block unbounded (always examined).
+static unsigned morton10(unsigned v)
+{
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+static void build_sorted_blocks(const float4 *tab, int n, float4 *sorted, float4 *blocks, int *orig)
+{
+    const int n_pad = (n + 63) & ~63;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = 0; i < n; ++i) {
+        const float c[3] = {tab[i].x, tab[i].y, tab[i].z};
+        for (int k = 0; k < 3; ++k)
+            if (std::isfinite(c[k])) {
+                lo[k] = std::min(lo[k], c[k]);
+                hi[k] = std::max(hi[k], c[k]);
+            }
+    }
+    std::vector<std::pair<unsigned, int>> keys((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const float c[3] = {tab[i].x, tab[i].y, tab[i].z};
+        unsigned q[3];
+        for (int k = 0; k < 3; ++k) {
+            const float span = hi[k] - lo[k];
+            const float t = (std::isfinite(c[k]) && span > 0) ? (c[k] - lo[k]) / span : 0.f;
+            q[k] = (unsigned)std::min(1023.f, std::max(0.f, t * 1023.f));
+        }
+        keys[i] = {morton10(q[0]) | (morton10(q[1]) << 1) | (morton10(q[2]) << 2), i};
+    }
+    std::sort(keys.begin(), keys.end());
+    for (int i = 0; i < n_pad; ++i) {
+        sorted[i] = i < n ? tab[keys[i].second] : make_float4(0.f, 0.f, 0.f, 0.f);
+        orig[i] = i < n ? keys[i].second : 0x7fffffff;
+    }
+    for (int b = 0; b < n_pad / 64; ++b) {
+        const int i0 = b * 64, i1 = std::min(n, i0 + 64);
+        double cx = 0, cy = 0, cz = 0;
+        for (int i = i0; i < i1; ++i) { cx += sorted[i].x; cy += sorted[i].y; cz += sorted[i].z; }
+        const double inv = 1.0 / std::max(1, i1 - i0);
+        cx *= inv; cy *= inv; cz *= inv;
+        double r = 0;
+        for (int i = i0; i < i1; ++i) {
+            const double dx = sorted[i].x - cx, dy = sorted[i].y - cy, dz = sorted[i].z - cz;
+            const double ri = std::sqrt(std::max(0.0, (double)sorted[i].w));
+            const double d = std::sqrt(dx * dx + dy * dy + dz * dz) + ri;
+            r = (d > r || d != d) ? d : r;   // a NaN sticks
+        }
+        float rf = (float)(r * 1.001 + 1e-3);
+        if (!(rf == rf) || !std::isfinite(cx + cy + cz)) { rf = INFINITY; cx = cy = cz = 0; }
+        blocks[b] = make_float4((float)cx, (float)cy, (float)cz, rf);
+    }
+}
+
 int rt_scene_set_spheres_async(rt_scene *s, const rt_sphere *host_spheres, int n, hipStream_t stream)
 {
     if (!s || n < 0 || (n > 0 && !host_spheres)) {
@@ -188,29 +253,45 @@ int rt_scene_set_spheres_async(rt_scene *s, const rt_sphere *host_spheres, int n
         rt_set_error("rt_scene_set_spheres: %d spheres exceed the limit of %d", n, kMaxSpheres);
         return RT_ERR_CAPACITY;
     }
-    if (n > s->cap_spheres) {
+    const int n_pad = (n + 63) & ~63, nb = n_pad / 64;
+    const size_t total = (size_t)n + (size_t)n_pad + (size_t)nb + ((size_t)n_pad + 3) / 4;   // in float4 units
+    if ((int)total > s->cap_spheres) {
         if (s->d_spheres) RT_HIP(hipFree(s->d_spheres));
         s->d_spheres = nullptr;
         s->cap_spheres = 0;
-        RT_HIP(hipMalloc((void **)&s->d_spheres, sizeof(float4) * (size_t)n));
-        s->cap_spheres = n;
+        RT_HIP(hipMalloc((void **)&s->d_spheres, sizeof(float4) * total));
+        s->cap_spheres = (int)total;
+        s->h_prev.clear();
     }
-    if (n > s->cap_stage) {
+    if ((int)total > s->cap_stage) {
+        if (s->stage_busy) RT_HIP(hipEventSynchronize(s->stage_done));
         if (s->h_stage) RT_HIP(hipHostFree(s->h_stage));
         s->h_stage = nullptr;
         s->cap_stage = 0;
-        RT_HIP(hipHostMalloc((void **)&s->h_stage, sizeof(float4) * (size_t)n, hipHostMallocDefault));
-        s->cap_stage = n;
+        RT_HIP(hipHostMalloc((void **)&s->h_stage, sizeof(float4) * total, hipHostMallocDefault));
+        s->cap_stage = (int)total;
     }
     if (n > 0) {
+        std::vector<float4> packed((size_t)n);
+        pack_spheres(host_spheres, n, packed.data());
+        if (s->n_spheres == n && s->h_prev.size() == (size_t)n &&
+            memcmp(s->h_prev.data(), packed.data(), sizeof(float4) * (size_t)n) == 0)
+            return RT_OK;   // unchanged since the last mirror: the device copy is current
         // the staging buffer is reused every frame: wait for the previous upload to have left it
         if (!s->stage_done) RT_HIP(hipEventCreateWithFlags(&s->stage_done, hipEventDisableTiming));
         if (s->stage_busy) RT_HIP(hipEventSynchronize(s->stage_done));
-        pack_spheres(host_spheres, n, s->h_stage);
-        RT_HIP(hipMemcpyAsync(s->d_spheres, s->h_stage, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, stream));
+        float4 *h_orig = s->h_stage, *h_sorted = h_orig + n, *h_blocks = h_sorted + n_pad;
+        int *h_idx = reinterpret_cast<int *>(h_blocks + nb);
+        memcpy(h_orig, packed.data(), sizeof(float4) * (size_t)n);
+        build_sorted_blocks(packed.data(), n, h_sorted, h_blocks, h_idx);
+        RT_HIP(hipMemcpyAsync(s->d_spheres, s->h_stage, sizeof(float4) * total, hipMemcpyHostToDevice, stream));
         RT_HIP(hipEventRecord(s->stage_done, stream));
         s->stage_busy = true;
+        s->h_prev.swap(packed);
+    } else {
+        s->h_prev.clear();
     }
+    s->n_blocks = nb;
     s->n_spheres = n;
     return RT_OK;
 }
@@ -566,6 +647,14 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
     fc->cubes = s->d_cubes;
     fc->n_planes = s->n_planes;
     fc->n_cubes = s->n_cubes;
+    {
+        const int n_pad = (s->n_spheres + 63) & ~63;
+        const float4 *base = s->d_spheres;
+        fc->sorted = base ? reinterpret_cast<const float *>(base + s->n_spheres) : nullptr;
+        fc->blocks = base ? reinterpret_cast<const float *>(base + s->n_spheres + n_pad) : nullptr;
+        fc->orig_idx = base ? reinterpret_cast<const int *>(base + s->n_spheres + n_pad + s->n_blocks) : nullptr;
+        fc->n_blocks = s->n_blocks;
+    }
     fc->tris = s->d_tris;
     fc->boxes = s->d_boxes;
     fc->tri_idx = s->d_tri_idx;

@@ -291,6 +291,24 @@ __device__ __forceinline__ bool beam_keeps(const Beam &b, float4 s)
     return (reach >= 0.f) && (d2 <= rad * rad * 1.0005f);
 }
 
+// A block of the Morton-ordered table: {centre, radius} of a sphere containing all
+// of its members (host side, rounded up). A member passes beam_keeps() only if
+// the block passes this test: the block's padded radius covers the member's
+// centre offset, its radius and its own padding sqrt(4e-5*|v|^2 + 1e-3)
+// (<= 6.4e-3*|v| + 0.032 with |v| <= |v_block| + r_block).
+__device__ __forceinline__ bool beam_keeps_block(const Beam &b, float4 blk)
+{
+    const float vx = blk.x - b.ax, vy = blk.y - b.ay, vz = blk.z - b.az;
+    const float vv = __builtin_fmaf(vx, vx, __builtin_fmaf(vy, vy, vz * vz));
+    const float sa = __builtin_fmaf(vx, b.ux, __builtin_fmaf(vy, b.uy, vz * b.uz));
+    const float d2 = __builtin_fmaxf(__builtin_fmaf(-sa, sa, vv), 0.f);
+    const float dist = __builtin_amdgcn_sqrtf(vv) * 1.0001f;
+    const float rc = __builtin_fmaf(6.5e-3f, dist + blk.w, blk.w) + 0.04f;
+    const float reach = sa + rc - b.smin;
+    const float rad = __builtin_fmaf(b.k, __builtin_fmaxf(reach, 0.f), b.r0) + rc;
+    return !(reach < 0.f) && !(d2 > rad * rad * 1.0005f);   // NaN / inf bounds keep the block
+}
+
 // The sphere table is either the workgroup's LDS copy (TABLDS, up to a few
 // thousand spheres) or read straight from global memory (any N; coalesced 16 B
 // per lane, L2-resident), in which case LDS only holds the survivor lists.
@@ -334,30 +352,64 @@ __device__ __forceinline__ bool beam_blocked_by(const Beam &b, float4 s)
     return ahead && (r2b > 0.f) && (lhs * lhs <= r2b);
 }
 
-// Returns the survivor count; with OCCL bit 30 flags "one sphere occludes the
-// whole beam" (count | 0x40000000).
-template <int STATS, bool TABLDS, bool OCCL = false>
-__device__ __forceinline__ int build_list(const float4 *tab, const float4 *__restrict__ gtab, int n, float4 *list,
-                                          const Beam &b, int lane, unsigned long long &n_cull)
+// Two-level cull over the Morton-ordered copy of the table: the blocks of 64 whose
+// bounding sphere the beam can touch, then their members. Survivors come out in
+// Morton order, which is fine for an any-hit; for the primary rays (ORDERED) their
+// list positions are carried along and the short list is put back in list order so
+// that the first index still wins ties (kernel.cu:1335). Returns the survivor count
+// (with OCCL, bit 30 flags "one sphere occludes the whole beam"); a count above
+// RT_LIST_CAP tells the caller to walk the whole table instead.
+template <int STATS, bool TABLDS, bool OCCL, bool ORDERED>
+__device__ __forceinline__ int build_list2(const float4 *tab, const RtFrameConsts &fc, int n, float4 *list, int *keys,
+                                           const Beam &b, int lane, unsigned long long &n_cull)
 {
+    const float4 *__restrict__ gsorted = reinterpret_cast<const float4 *>(fc.sorted);
+    const float4 *__restrict__ gblocks = reinterpret_cast<const float4 *>(fc.blocks);
+    const int nb = fc.n_blocks;
     int count = 0;
     bool blk = false;
-    for (int base = 0; base < n; base += 64) {
-        const int i = base + lane;
-        const float4 s = table_at<TABLDS>(tab, gtab, i < n ? i : n - 1);
-        const bool keep = (i < n) && beam_keeps(b, s);
-        if (OCCL) blk = blk || (keep && beam_blocked_by(b, s));
-        const unsigned long long m = __ballot(keep);
-        const int pos = count + lane_prefix(m);
-        if (keep && pos < RT_LIST_CAP) list[pos] = s;
-        count += __popcll(m);
+    for (int bbase = 0; bbase < nb; bbase += 64) {
+        const int bi = bbase + lane;
+        const bool kb = (bi < nb) && beam_keeps_block(b, gblocks[bi < nb ? bi : nb - 1]);
+        unsigned long long bm = __ballot(kb);
         if (STATS == 1) n_cull += 64;
+        while (bm) {
+            const int k = __builtin_ctzll(bm);
+            bm &= bm - 1;
+            const int i = (bbase + k) * 64 + lane;   // < n_pad: always inside the table
+            const float4 s = table_at<TABLDS>(tab, gsorted, i);
+            const bool keep = (i < n) && beam_keeps(b, s);
+            if (OCCL) blk = blk || (keep && beam_blocked_by(b, s));
+            const unsigned long long m = __ballot(keep);
+            const int pos = count + lane_prefix(m);
+            if (keep && pos < RT_LIST_CAP) {
+                list[pos] = s;
+                if (ORDERED) keys[pos] = fc.orig_idx[i];
+            }
+            count += __popcll(m);
+            if (STATS == 1) n_cull += 64;
+        }
     }
     wave_lds_sync();
+    if (ORDERED) {
+        if (count > 64) {
+            count = RT_LIST_CAP + 1;     // too long to reorder in one step: caller walks the table
+        } else if (count > 1) {
+            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+            int key = 0, rank = 0;
+            if (lane < count) {
+                e = list[lane];
+                key = keys[lane];
+            }
+            for (int j = 0; j < count; ++j) rank += (keys[j] < key) ? 1 : 0;   // list positions are distinct
+            wave_lds_sync();
+            if (lane < count) list[rank] = e;
+            wave_lds_sync();
+        }
+    }
     if (OCCL && __any(blk)) count |= 0x40000000;
     return count;
 }
-
 
 // Leaf boxes of the mesh that the beam can touch, as indices in leaf order. A ray
 // tests a leaf's triangles only after passing the leaf's slab test, i.e. only if
@@ -512,11 +564,16 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
     // ---- stage the sphere table into LDS (coalesced 16 B/lane) ----
     float4 *tab = lds;
     if constexpr (TABLDS) {
-        for (int i = tid; i < n; i += 64 * RT_WAVES_PER_WG) tab[i] = spheres[i];
+        // the culling kernels stage the Morton-ordered copy (whole blocks, n_pad entries);
+        // the brute-force kernels stage the list as it is
+        const float4 *src = CULL ? reinterpret_cast<const float4 *>(fc.sorted) : spheres;
+        for (int i = tid; i < (CULL ? n_pad : n); i += 64 * RT_WAVES_PER_WG) tab[i] = src[i];
         __syncthreads();
     }
     float4 *mylist = lds + (TABLDS ? n_pad : 0) + wave * RT_LIST_CAP;
-    int *myboxes = reinterpret_cast<int *>(lds + (TABLDS ? n_pad : 0) + RT_WAVES_PER_WG * RT_LIST_CAP) + wave * RT_BOX_CAP;
+    int *mykeys = reinterpret_cast<int *>(lds + (TABLDS ? n_pad : 0) + RT_WAVES_PER_WG * RT_LIST_CAP) + wave * RT_LIST_CAP;
+    int *myboxes = reinterpret_cast<int *>(lds + (TABLDS ? n_pad : 0) + RT_WAVES_PER_WG * RT_LIST_CAP) +
+                   RT_WAVES_PER_WG * RT_LIST_CAP + wave * RT_BOX_CAP;
 
     const int tile_x = (blockIdx.x * WGX + (wave % WGX)) * TW;
     // local row -> global row: a contiguous band, or row blocks dealt round-robin
@@ -595,7 +652,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
             b.smax = 0.f;
             b.r0 = 1.0e-4f;
             if (ok) {
-                const int c = build_list<STATS, TABLDS>(tab, spheres, n, mylist, b, lane, st_cull);
+                const int c = build_list2<STATS, TABLDS, false, true>(tab, fc, n, mylist, mykeys, b, lane, st_cull);
                 if (c <= RT_LIST_CAP) {
                     p_use_list = true;
                     pcount = c;
@@ -643,10 +700,16 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                 }
             }
         }
-        float4 pcur = pcount > 0 ? entry_at<TABLDS>(p_use_list, mylist, tab, spheres, 0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // without a list the table is walked in list order: from global memory in the culling
+        // kernels (their LDS copy is Morton-ordered), from LDS in the brute-force ones
+        auto primary_entry = [&](int e) -> float4 {
+            if (CULL) return p_use_list ? mylist[e] : spheres[e];
+            return entry_at<TABLDS>(false, mylist, tab, spheres, e);
+        };
+        float4 pcur = pcount > 0 ? primary_entry(0) : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int e = 0; e < pcount; ++e) {
             const float4 s = pcur;
-            pcur = entry_at<TABLDS>(p_use_list, mylist, tab, spheres, e + 1 < pcount ? e + 1 : e);   // one entry in flight
+            pcur = primary_entry(e + 1 < pcount ? e + 1 : e);   // one entry in flight
             const Quad q = quadratic(pr, s);
             bool need = (q.disc >= 0.f);
             if (!fc.force_slow) need = need && !(q.h > 0.f && q.disc < q.BB * RT_BEHIND_FACTOR);
@@ -912,7 +975,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                         // every lit lane: unshadowed = 0, b = 0, and the light adds exactly
                         // nothing -- the sample construction and the tests are skipped.
                         const bool may_skip = !fc.force_slow && !(fc.ablate & 64) && __all(!lit || zero_ok);
-                        const int cb = build_list<STATS, TABLDS, true>(tab, spheres, n, mylist, b, lane, st_cull);
+                        const int cb = build_list2<STATS, TABLDS, true, false>(tab, fc, n, mylist, mykeys, b, lane, st_cull);
                         const int c = cb & 0x3fffffff;
                         if (may_skip && (cb & 0x40000000)) {
                             if (STATS == 1) hist[7] += 1;
@@ -982,9 +1045,10 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                     bool shadowed = !lit;   // lanes outside the group (or unlit) are simply done
                     const int scount_j = (fc.ablate & 1) ? 0 : scount;
                     if (scount_j > 0) {
-                        float4 cur = entry_at<TABLDS>(s_use_list, mylist, tab, spheres, 0);
+                        const float4 *gtab = CULL ? reinterpret_cast<const float4 *>(fc.sorted) : spheres;
+                        float4 cur = entry_at<TABLDS>(s_use_list, mylist, tab, gtab, 0);
                         for (int e = 0; e < scount_j; ++e) {
-                            const float4 nxt = entry_at<TABLDS>(s_use_list, mylist, tab, spheres,
+                            const float4 nxt = entry_at<TABLDS>(s_use_list, mylist, tab, gtab,
                                                                 e + 1 < scount_j ? e + 1 : e);   // one entry in flight
                             shadow_test(sr, cur, shadowed, fc.force_slow != 0);
                             cur = nxt;
@@ -1207,6 +1271,7 @@ extern "C" hipError_t rt_dev_launch_trace(const RtFrameConsts *fc, const float4 
     if (fc->n_boxes > 0 && (tile_w != 8 || stats != 0)) return hipErrorNotSupported;   // mesh scenes: default tile only
     const int n_pad = (fc->n_spheres + 63) & ~63;
     const size_t lds_bytes = (size_t)((table_in_lds ? n_pad : 0) + RT_WAVES_PER_WG * RT_LIST_CAP) * sizeof(float4) +
+                             (size_t)RT_WAVES_PER_WG * RT_LIST_CAP * sizeof(int) +   // list positions (primary order)
                              (fc->n_boxes > 0 ? (size_t)RT_WAVES_PER_WG * RT_BOX_CAP * sizeof(int) : 0);
     const int band_h = fc->local_rows;
     const int th = 64 / tile_w;
