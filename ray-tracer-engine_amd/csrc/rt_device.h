@@ -22,6 +22,9 @@
                                // that add 0.6 GB of scratch writes per frame.
 #endif
 #define RT_WAVES_PER_WG 4
+#ifndef RT_BLOCK
+#define RT_BLOCK 16             // spheres per block of the Morton-ordered table (divides 64)
+#endif
 #define RT_BOX_CAP 128          // leaf-box list capacity per wave (ints in LDS, mesh scenes only)
 #ifndef RT_TABLE_LDS_MAX
 #define RT_TABLE_LDS_MAX 1024   // sphere tables up to this size are staged in LDS (16 KiB); measured at

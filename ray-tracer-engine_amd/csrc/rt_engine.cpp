@@ -183,7 +183,7 @@ static void pack_spheres(const rt_sphere *src, int n, float4 *dst)
 }
 
 // Morton order of the centres (10 bits per axis over the scene's bounds), blocks of
-// 64 consecutive spheres, and for each block a sphere that contains every member
+// RT_BLOCK consecutive spheres, and for each block a sphere that contains every member
 // (centre = mean of the members' centres, radius = max |c_i - centre| + R_i, rounded
 // up). Spheres with non-finite data make their block unbounded (always examined).
 static unsigned morton10(unsigned v)
@@ -224,8 +224,12 @@ static void build_sorted_blocks(const float4 *tab, int n, float4 *sorted, float4
         sorted[i] = i < n ? tab[keys[i].second] : make_float4(0.f, 0.f, 0.f, 0.f);
         orig[i] = i < n ? keys[i].second : 0x7fffffff;
     }
-    for (int b = 0; b < n_pad / 64; ++b) {
-        const int i0 = b * 64, i1 = std::min(n, i0 + 64);
+    for (int b = 0; b < n_pad / RT_BLOCK; ++b) {
+        const int i0 = b * RT_BLOCK, i1 = std::min(n, i0 + RT_BLOCK);
+        if (i0 >= n) {   // padding block: nothing in it, never examined
+            blocks[b] = make_float4(0.f, 0.f, 0.f, -1.f);
+            continue;
+        }
         double cx = 0, cy = 0, cz = 0;
         for (int i = i0; i < i1; ++i) { cx += sorted[i].x; cy += sorted[i].y; cz += sorted[i].z; }
         const double inv = 1.0 / std::max(1, i1 - i0);
@@ -253,7 +257,7 @@ int rt_scene_set_spheres_async(rt_scene *s, const rt_sphere *host_spheres, int n
         rt_set_error("rt_scene_set_spheres: %d spheres exceed the limit of %d", n, kMaxSpheres);
         return RT_ERR_CAPACITY;
     }
-    const int n_pad = (n + 63) & ~63, nb = n_pad / 64;
+    const int n_pad = (n + 63) & ~63, nb = n_pad / RT_BLOCK;
     const size_t total = (size_t)n + (size_t)n_pad + (size_t)nb + ((size_t)n_pad + 3) / 4;   // in float4 units
     if ((int)total > s->cap_spheres) {
         if (s->d_spheres) RT_HIP(hipFree(s->d_spheres));

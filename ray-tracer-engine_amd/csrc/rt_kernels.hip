@@ -352,8 +352,8 @@ __device__ __forceinline__ bool beam_blocked_by(const Beam &b, float4 s)
     return ahead && (r2b > 0.f) && (lhs * lhs <= r2b);
 }
 
-// Two-level cull over the Morton-ordered copy of the table: the blocks of 64 whose
-// bounding sphere the beam can touch, then their members. Survivors come out in
+// Two-level cull over the Morton-ordered copy of the table: the blocks of RT_BLOCK whose
+// bounding sphere the beam can touch, then their members (64/RT_BLOCK blocks per step). Survivors come out in
 // Morton order, which is fine for an any-hit; for the primary rays (ORDERED) their
 // list positions are carried along and the short list is put back in list order so
 // that the first index still wins ties (kernel.cu:1335). Returns the survivor count
@@ -368,17 +368,26 @@ __device__ __forceinline__ int build_list2(const float4 *tab, const RtFrameConst
     const int nb = fc.n_blocks;
     int count = 0;
     bool blk = false;
+    constexpr int G = 64 / RT_BLOCK;           // blocks examined side by side in one step
+    const int grp = lane / RT_BLOCK, sub = lane % RT_BLOCK;
     for (int bbase = 0; bbase < nb; bbase += 64) {
         const int bi = bbase + lane;
-        const bool kb = (bi < nb) && beam_keeps_block(b, gblocks[bi < nb ? bi : nb - 1]);
+        const float4 bb = gblocks[bi < nb ? bi : nb - 1];
+        const bool kb = (bi < nb) && (bb.w >= 0.f || bb.w != bb.w) && beam_keeps_block(b, bb);   // w < 0: padding block
         unsigned long long bm = __ballot(kb);
         if (STATS == 1) n_cull += 64;
         while (bm) {
-            const int k = __builtin_ctzll(bm);
-            bm &= bm - 1;
-            const int i = (bbase + k) * 64 + lane;   // < n_pad: always inside the table
+            // the next G marked blocks, one per group of RT_BLOCK lanes
+            int mine = -1;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int k = bm ? __builtin_ctzll(bm) : -1;
+                bm &= bm - 1;
+                mine = (grp == g) ? k : mine;
+            }
+            const int i = (bbase + (mine < 0 ? 0 : mine)) * RT_BLOCK + sub;   // inside the padded table
             const float4 s = table_at<TABLDS>(tab, gsorted, i);
-            const bool keep = (i < n) && beam_keeps(b, s);
+            const bool keep = (mine >= 0) && (i < n) && beam_keeps(b, s);
             if (OCCL) blk = blk || (keep && beam_blocked_by(b, s));
             const unsigned long long m = __ballot(keep);
             const int pos = count + lane_prefix(m);
