@@ -21,7 +21,9 @@
                                // (HBM writes = the 166 MB of pixels); 6 -> 1.43 ms but spills
                                // that add 0.6 GB of scratch writes per frame.
 #endif
-#define RT_WAVES_PER_WG 4
+#ifndef RT_WAVES_PER_WG
+#define RT_WAVES_PER_WG 4         // wave tiles per workgroup (1, 2 or 4)
+#endif
 #ifndef RT_BLOCK
 #define RT_BLOCK 16             // spheres per block of the Morton-ordered table (divides 64)
 #endif

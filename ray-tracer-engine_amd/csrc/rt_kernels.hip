@@ -33,6 +33,9 @@
 
 namespace {
 
+#ifndef RT_EXP_NOLDSBTAB
+#define RT_EXP_NOLDSBTAB 0
+#endif
 struct V3 {
     float x, y, z;
 };
@@ -43,31 +46,54 @@ struct V3 {
 // Wave-wide reductions on the VALU's DPP path (no LDS round trips): butterfly
 // inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 carry the row
 // results upward so that lane 63 holds the reduction, which is broadcast back
-// through an SGPR. All 64 lanes must be active (callers are in uniform control flow).
+// through an SGPR (only lane 63 is meaningful after the broadcast steps, which run on all
+// rows: lanes without a source get `old`). All 64 lanes must be active (callers are in
+// uniform control flow). `old` is the operation's identity, so that the compiler folds each
+// move into the operation (one v_max_u32_dpp / v_add_f32_dpp per step, nothing to canonicalise).
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_move(float v)
+__device__ __forceinline__ int dpp_move0(int v)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
-                                                                  CTRL, ROW_MASK, 0xf, false));
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
 }
-#define RT_WAVE_REDUCE(NAME, OP)                                                   \
-    __device__ __forceinline__ float NAME(float v)                                 \
-    {                                                                              \
-        v = OP(v, dpp_move<0xB1, 0xf>(v));  /* quad_perm [1,0,3,2]  */              \
-        v = OP(v, dpp_move<0x4E, 0xf>(v));  /* quad_perm [2,3,0,1]  */              \
-        v = OP(v, dpp_move<0x141, 0xf>(v)); /* row_half_mirror      */              \
-        v = OP(v, dpp_move<0x140, 0xf>(v)); /* row_mirror           */              \
-        v = OP(v, dpp_move<0x142, 0xa>(v)); /* row_bcast:15 -> rows 1,3 */          \
-        v = OP(v, dpp_move<0x143, 0xc>(v)); /* row_bcast:31 -> rows 2,3 */          \
-        return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); \
+// max over the wave of NON-NEGATIVE floats, compared as unsigned integers (same order);
+// a NaN compares above +inf and therefore survives into the result.
+__device__ __forceinline__ float wave_max(float f)
+{
+    unsigned v = __builtin_bit_cast(unsigned, f);
+#define RT_STEP(CTRL, MASK) { const unsigned m = (unsigned)dpp_move0<CTRL, MASK>((int)v); v = v > m ? v : m; }
+    RT_STEP(0xB1, 0xf)    /* quad_perm [1,0,3,2]  */
+    RT_STEP(0x4E, 0xf)    /* quad_perm [2,3,0,1]  */
+    RT_STEP(0x141, 0xf)   /* row_half_mirror      */
+    RT_STEP(0x140, 0xf)   /* row_mirror           */
+    RT_STEP(0x142, 0xf)   /* row_bcast:15 -> rows 1,3 */
+    RT_STEP(0x143, 0xf)   /* row_bcast:31 -> rows 2,3 */
+#undef RT_STEP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)v, 63));
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#define RT_STEP(CTRL, MASK) v = v + __builtin_bit_cast(float, dpp_move0<CTRL, MASK>(__builtin_bit_cast(int, v)));
+    RT_STEP(0xB1, 0xf) RT_STEP(0x4E, 0xf) RT_STEP(0x141, 0xf) RT_STEP(0x140, 0xf) RT_STEP(0x142, 0xf) RT_STEP(0x143, 0xf)
+#undef RT_STEP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// three sums at once, their steps interleaved (a DPP read needs two wait states after the
+// write of its source: with three chains in flight no s_nop is needed)
+__device__ __forceinline__ void wave_sum3(float &a, float &b, float &c)
+{
+#define RT_STEP(CTRL, MASK)                                                                    \
+    {                                                                                          \
+        const float ta = __builtin_bit_cast(float, dpp_move0<CTRL, MASK>(__builtin_bit_cast(int, a))); \
+        const float tb = __builtin_bit_cast(float, dpp_move0<CTRL, MASK>(__builtin_bit_cast(int, b))); \
+        const float tc = __builtin_bit_cast(float, dpp_move0<CTRL, MASK>(__builtin_bit_cast(int, c))); \
+        a = a + ta; b = b + tb; c = c + tc;                                                    \
     }
-__device__ __forceinline__ float rt_fmax(float a, float b) { return __builtin_fmaxf(a, b); }
-__device__ __forceinline__ float rt_fmin(float a, float b) { return __builtin_fminf(a, b); }
-__device__ __forceinline__ float rt_fadd(float a, float b) { return a + b; }
-RT_WAVE_REDUCE(wave_max, rt_fmax)
-RT_WAVE_REDUCE(wave_min, rt_fmin)
-RT_WAVE_REDUCE(wave_sum, rt_fadd)
-#undef RT_WAVE_REDUCE
+    RT_STEP(0xB1, 0xf) RT_STEP(0x4E, 0xf) RT_STEP(0x141, 0xf) RT_STEP(0x140, 0xf) RT_STEP(0x142, 0xf) RT_STEP(0x143, 0xf)
+#undef RT_STEP
+    a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 63));
+    b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 63));
+    c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c), 63));
+}
 __device__ __forceinline__ float uniform(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
@@ -352,6 +378,33 @@ __device__ __forceinline__ bool beam_blocked_by(const Beam &b, float4 s)
     return ahead && (r2b > 0.f) && (lhs * lhs <= r2b);
 }
 
+// beam_keeps() and beam_blocked_by() in one straight line for the culling loop: the two share
+// |v|^2, the axial coordinate and the distance from the axis, and written with short-circuit
+// conditions the compiler wraps every clause in its own exec-mask region (a third of the
+// loop's instructions). `blocked` is only meaningful for kept entries.
+template <bool OCCL>
+__device__ __forceinline__ bool beam_member_test(const Beam &b, float4 s, bool enable, bool &blocked)
+{
+    const float vx = s.x - b.ax, vy = s.y - b.ay, vz = s.z - b.az;
+    const float vv = __builtin_fmaf(vx, vx, __builtin_fmaf(vy, vy, vz * vz));
+    const float sa = __builtin_fmaf(vx, b.ux, __builtin_fmaf(vy, b.uy, vz * b.uz));
+    const float d2 = __builtin_fmaxf(__builtin_fmaf(-sa, sa, vv), 0.f);
+    const float pad = __builtin_fmaf(4.0e-5f, vv, 1.0e-3f);
+    const float rc = __builtin_amdgcn_sqrtf(s.w + pad) * 1.0001f;
+    const float reach = sa + rc - b.smin;
+    const float rad = __builtin_fmaf(b.k, __builtin_fmaxf(reach, 0.f), b.r0) + rc;
+    const bool keep = enable & (reach >= 0.f) & (d2 <= rad * rad * 1.0005f);
+    if (OCCL) {
+        const float r2b = s.w - pad;                                       // shrunken radius^2
+        const float rr = __builtin_amdgcn_sqrtf(s.w);
+        const bool ahead = (sa - b.smax) >= __builtin_fmaf(rr, 1.001f, 0.01f);
+        const float rho = __builtin_fmaf(b.k, sa - b.smin, b.r0);
+        const float lhs = __builtin_fmaf(__builtin_amdgcn_sqrtf(d2) + rho, 1.001f, 1.0e-4f);
+        blocked = blocked | (keep & ahead & (r2b > 0.f) & (lhs * lhs <= r2b));
+    }
+    return keep;
+}
+
 // Two-level cull over the Morton-ordered copy of the table: the blocks of RT_BLOCK whose
 // bounding sphere the beam can touch, then their members (64/RT_BLOCK blocks per step). Survivors come out in
 // Morton order, which is fine for an any-hit; for the primary rays (ORDERED) their
@@ -361,7 +414,7 @@ __device__ __forceinline__ bool beam_blocked_by(const Beam &b, float4 s)
 // RT_LIST_CAP tells the caller to walk the whole table instead.
 template <int STATS, bool TABLDS, bool OCCL, bool ORDERED>
 __device__ __forceinline__ int build_list2(const float4 *tab, const RtFrameConsts &fc, int n, float4 *list, int *keys,
-                                           const Beam &b, int lane, unsigned long long &n_cull)
+                                           int *blist, const Beam &b, int lane, unsigned long long &n_cull)
 {
     const float4 *__restrict__ gsorted = reinterpret_cast<const float4 *>(fc.sorted);
     const float4 *__restrict__ gblocks = reinterpret_cast<const float4 *>(fc.blocks);
@@ -374,21 +427,20 @@ __device__ __forceinline__ int build_list2(const float4 *tab, const RtFrameConst
         const int bi = bbase + lane;
         const float4 bb = gblocks[bi < nb ? bi : nb - 1];
         const bool kb = (bi < nb) && (bb.w >= 0.f || bb.w != bb.w) && beam_keeps_block(b, bb);   // w < 0: padding block
-        unsigned long long bm = __ballot(kb);
+        const unsigned long long bm = __ballot(kb);
         if (STATS == 1) n_cull += 64;
-        while (bm) {
-            // the next G marked blocks, one per group of RT_BLOCK lanes
-            int mine = -1;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const int k = bm ? __builtin_ctzll(bm) : -1;
-                bm &= bm - 1;
-                mine = (grp == g) ? k : mine;
-            }
-            const int i = (bbase + (mine < 0 ? 0 : mine)) * RT_BLOCK + sub;   // inside the padded table
+        // the marked blocks, compacted into the wave's block list; then G of them per step,
+        // one per group of RT_BLOCK lanes (next step's block number read one step ahead)
+        const int marked = __popcll(bm);
+        if (kb) blist[lane_prefix(bm)] = bi;
+        wave_lds_sync();
+        int cur = (grp < marked) ? blist[grp] : -1;
+        for (int t = 0; t < marked; t += G) {
+            const int nslot = t + G + grp;
+            const int nxt = (nslot < marked) ? blist[nslot] : -1;
+            const int i = (cur < 0 ? 0 : cur) * RT_BLOCK + sub;   // inside the padded table
             const float4 s = table_at<TABLDS>(tab, gsorted, i);
-            const bool keep = (mine >= 0) && (i < n) && beam_keeps(b, s);
-            if (OCCL) blk = blk || (keep && beam_blocked_by(b, s));
+            const bool keep = beam_member_test<OCCL>(b, s, (cur >= 0) & (i < n), blk);
             const unsigned long long m = __ballot(keep);
             const int pos = count + lane_prefix(m);
             if (keep && pos < RT_LIST_CAP) {
@@ -397,7 +449,9 @@ __device__ __forceinline__ int build_list2(const float4 *tab, const RtFrameConst
             }
             count += __popcll(m);
             if (STATS == 1) n_cull += 64;
+            cur = nxt;
         }
+        if (bbase + 64 < nb) wave_lds_sync();   // the next 64 blocks reuse the block list
     }
     wave_lds_sync();
     if (ORDERED) {
@@ -561,7 +615,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                                                                      const float4 *__restrict__ spheres)
 {
     constexpr int TH = 64 / TW;
-    constexpr int WGX = (TW <= 16) ? 2 : 1;   // wave tiles per workgroup in x
+    constexpr int WGX = (TW <= 16 && RT_WAVES_PER_WG >= 2) ? 2 : 1;   // wave tiles per workgroup in x
     extern __shared__ float4 lds[];
 
     const int tid = threadIdx.x;
@@ -581,8 +635,17 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
     }
     float4 *mylist = lds + (TABLDS ? n_pad : 0) + wave * RT_LIST_CAP;
     int *mykeys = reinterpret_cast<int *>(lds + (TABLDS ? n_pad : 0) + RT_WAVES_PER_WG * RT_LIST_CAP) + wave * RT_LIST_CAP;
+    // b after n float+=double steps of 0.1 (brightness_steps), one 16-entry copy per wave: a
+    // per-lane n then costs one LDS read instead of a ten-deep select chain per light
+    float *mybtab = reinterpret_cast<float *>(lds + (TABLDS ? n_pad : 0) + RT_WAVES_PER_WG * RT_LIST_CAP) +
+                    RT_WAVES_PER_WG * RT_LIST_CAP + wave * 16;
+    // marked blocks of one culling pass (at most 64 at a time)
+    int *myblks = reinterpret_cast<int *>(lds + (TABLDS ? n_pad : 0) + RT_WAVES_PER_WG * RT_LIST_CAP) +
+                  RT_WAVES_PER_WG * (RT_LIST_CAP + 16) + wave * 64;
     int *myboxes = reinterpret_cast<int *>(lds + (TABLDS ? n_pad : 0) + RT_WAVES_PER_WG * RT_LIST_CAP) +
-                   RT_WAVES_PER_WG * RT_LIST_CAP + wave * RT_BOX_CAP;
+                   RT_WAVES_PER_WG * (RT_LIST_CAP + 16 + 64) + wave * RT_BOX_CAP;
+    if (lane < 16) mybtab[lane] = brightness_steps(lane);
+    wave_lds_sync();
 
     const int tile_x = (blockIdx.x * WGX + (wave % WGX)) * TW;
     // local row -> global row: a contiguous band, or row blocks dealt round-robin
@@ -645,7 +708,8 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
         int pbcount = MESH ? fc.n_boxes : 0;
         if (CULL) {
             // cone around the tile's mean direction, apex at the (shared) origin
-            float sx = wave_sum(D.x), sy = wave_sum(D.y), sz = wave_sum(D.z);
+            float sx = D.x, sy = D.y, sz = D.z;
+            wave_sum3(sx, sy, sz);
             const float inv = __builtin_amdgcn_rsqf(__builtin_fmaf(sx, sx, __builtin_fmaf(sy, sy, sz * sz)));
             Beam b;
             b.ux = uniform(sx * inv); b.uy = uniform(sy * inv); b.uz = uniform(sz * inv);
@@ -661,7 +725,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
             b.smax = 0.f;
             b.r0 = 1.0e-4f;
             if (ok) {
-                const int c = build_list2<STATS, TABLDS, false, true>(tab, fc, n, mylist, mykeys, b, lane, st_cull);
+                const int c = build_list2<STATS, TABLDS, false, true>(tab, fc, n, mylist, mykeys, myblks, b, lane, st_cull);
                 if (c <= RT_LIST_CAP) {
                     p_use_list = true;
                     pcount = c;
@@ -865,6 +929,19 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
             for (int g = 0; g < n_groups; ++g) {
             const bool inc = hit && (gid == g);
             if (STATS == 1) st_clusters += 1;
+            // The group's ray origins, bounded once for all lights: a ball around the first
+            // member's `start`. (Per-light axial and perpendicular extents would be a little
+            // tighter, for three more wave reductions per light; the patch a tile sees of one
+            // primitive is small against the spheres it is culled against.)
+            float g_ax = 0.f, g_ay = 0.f, g_az = 0.f, g_r2 = 0.f;
+            if (CULL) {
+                const int glead = __builtin_ctzll(__ballot(inc));
+                g_ax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, start.x), glead));
+                g_ay = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, start.y), glead));
+                g_az = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, start.z), glead));
+                const float ox = start.x - g_ax, oy = start.y - g_ay, oz = start.z - g_az;
+                g_r2 = uniform(wave_max(inc ? __builtin_fmaf(ox, ox, __builtin_fmaf(oy, oy, oz * oz)) : 0.f));
+            }
             for (int li = 0; li < fc.n_lights; ++li) {
                 const RtLightDev L = fc.lights[li];
                 const V3 lpos{L.px, L.py, L.pz};
@@ -922,36 +999,29 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                         const float m00 = c + ax * ax, m01 = ax * ay * omc, m02 = -ay * sn;
                         const float m10 = m01, m11 = c + ay * ay * omc, m12 = -ax * sn;
                         const float m20 = -ay * sn, m21 = ax * sn, m22 = c;
-                        // P = toL x (0,1,0) = (-toL.z, 0, toL.x)
-                        const float ex = lpos.x - toL.z * L.size - start.x;
-                        const float ey = lpos.y - start.y;
-                        const float ez = lpos.z + toL.x * L.size - start.z;
-                        const float re = __builtin_amdgcn_rsqf(ex * ex + ey * ey + ez * ez);
-                        const float dte = (toL.x * ex + toL.y * ey + toL.z * ez) * re;
-                        const float angle = __cosf(2.f * dte);
                         // A sample direction is w_j = l.pos - r_j with r_j = x_j R0 + y_j R1 + z_j R2
-                        // (rows of the matrix) and |(x,y,z)| = 1. Its deviation from u = l.pos/|l.pos|:
+                        // (rows of the matrix), (x_j, y_j) = sqrt(1 - z_j^2) (cos phi_j, sin phi_j) and
+                        // |z_j| <= 1. Its deviation from u = l.pos/|l.pos|:
                         // sin = |w x u| / |w| = |r x u| / |w| (l.pos x u = 0), with
-                        // r x u = x (R0 x u) + y (R1 x u) + z (R2 x u) and |w| >= |l.pos| - ||M||_F.
+                        // r x u = x A + y B + z C, A = R0 x u, B = R1 x u, C = R2 x u, and
+                        // |w| >= |l.pos| - ||M||_F. For ANY phi and any |z| <= 1:
+                        // |x A + y B + z C| <= sqrt(1 - z^2) sigma + |z| |C| <= sqrt(sigma^2 + |C|^2),
+                        // sigma^2 the larger eigenvalue of the Gram matrix [[A.A, A.B], [A.B, B.B]].
+                        // (The ten samples themselves come within a few per cent of this bound; walking
+                        // them cost 250 instructions per light.) A NaN or inf anywhere makes kmax2 a NaN,
+                        // which switches culling off below.
                         const float a0x = m01 * b.uz - m02 * b.uy, a0y = m02 * b.ux - m00 * b.uz, a0z = m00 * b.uy - m01 * b.ux;
                         const float a1x = m11 * b.uz - m12 * b.uy, a1y = m12 * b.ux - m10 * b.uz, a1z = m10 * b.uy - m11 * b.ux;
                         const float a2x = m21 * b.uz - m22 * b.uy, a2y = m22 * b.ux - m20 * b.uz, a2z = m20 * b.uy - m21 * b.ux;
                         const float frob2 = m00 * m00 + m01 * m01 + m02 * m02 + m10 * m10 + m11 * m11 + m12 * m12 +
                                             m20 * m20 + m21 * m21 + m22 * m22;
                         const float den = L.pos_len - __builtin_amdgcn_sqrtf(frob2) * 1.001f;
-                        float kmax2 = 0.f;
-#pragma unroll 1   // rolled: the unrolled form keeps 30 table values live in VGPRs
-                        for (int j = 0; j < RT_SHADOW_SAMPLES; ++j) {
-                            const float z = __builtin_fmaf(fc.jf[j], 1.f - angle, angle);
-                            const float sq = __builtin_amdgcn_sqrtf(__builtin_fmaxf(__builtin_fmaf(-z, z, 1.f), 0.f));
-                            const float x = sq * fc.jcos[j], y = sq * fc.jsin[j];
-                            const float kx = __builtin_fmaf(x, a0x, __builtin_fmaf(y, a1x, z * a2x));
-                            const float ky = __builtin_fmaf(x, a0y, __builtin_fmaf(y, a1y, z * a2y));
-                            const float kz = __builtin_fmaf(x, a0z, __builtin_fmaf(y, a1z, z * a2z));
-                            const float k2 = __builtin_fmaf(kx, kx, __builtin_fmaf(ky, ky, kz * kz));
-                            // not fmaxf: a NaN must poison the bound so that culling is skipped
-                            kmax2 = (k2 > kmax2 || k2 != k2) ? k2 : kmax2;
-                        }
+                        const float gaa = a0x * a0x + a0y * a0y + a0z * a0z;
+                        const float gbb = a1x * a1x + a1y * a1y + a1z * a1z;
+                        const float gab = a0x * a1x + a0y * a1y + a0z * a1z;
+                        const float gcc = a2x * a2x + a2y * a2y + a2z * a2z;
+                        const float hd = 0.5f * (gaa - gbb);
+                        const float kmax2 = (0.5f * (gaa + gbb) + __builtin_amdgcn_sqrtf(hd * hd + gab * gab)) * 1.001f + gcc;
                         // a light closer to the origin than the matrix can reach has no usable bound
                         const float rden = __builtin_amdgcn_rcpf(den);
                         smax2 = (den > 0.05f * L.pos_len) ? kmax2 * rden * rden * 1.0001f : __builtin_nanf("");
@@ -962,21 +1032,12 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                     const float s2w = uniform(wave_max(smax2));
                     const float snw = __builtin_amdgcn_sqrtf(s2w) * 1.02f + 2.0e-3f;
                     b.k = snw * __builtin_amdgcn_rsqf(__builtin_fmaxf(1.f - snw * snw, 0.05f));
-                    // origins: axis through the first participating lane's start
-                    const int lead = __builtin_ctzll(__ballot(lit));
-                    b.ax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, start.x), lead));
-                    b.ay = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, start.y), lead));
-                    b.az = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, start.z), lead));
-                    const float ox = start.x - b.ax, oy = start.y - b.ay, oz = start.z - b.az;
-                    const float so = ox * b.ux + oy * b.uy + oz * b.uz;
-                    const float perp2 = __builtin_fmaxf(ox * ox + oy * oy + oz * oz - so * so, 0.f);
-                    const float r2 = uniform(wave_max(lit ? perp2 : 0.f));
-                    const float smin = uniform(wave_min(lit ? so : 3.0e38f));
-                    const float smax = uniform(wave_max(lit ? so : -3.0e38f));
-                    ok = ok && (r2 < 1.0e30f) && (smin > -1.0e30f);
-                    b.r0 = __builtin_amdgcn_sqrtf(r2) * 1.001f + 1.0e-3f;
-                    b.smin = smin - 1.0e-3f - 1.0e-4f * __builtin_fabsf(smin);
-                    b.smax = smax + 1.0e-3f + 1.0e-4f * __builtin_fabsf(smax);
+                    // origins: the group's ball (see above), centred on the axis
+                    b.ax = g_ax; b.ay = g_ay; b.az = g_az;
+                    ok = ok && (g_r2 < 1.0e30f);
+                    b.r0 = __builtin_amdgcn_sqrtf(g_r2) * 1.001f + 1.0e-3f;
+                    b.smin = -b.r0;
+                    b.smax = b.r0;
                     phase(4);
                     if (fc.ablate & 4) { ok = false; scount = 0; }
                     if (ok) {
@@ -984,7 +1045,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                         // every lit lane: unshadowed = 0, b = 0, and the light adds exactly
                         // nothing -- the sample construction and the tests are skipped.
                         const bool may_skip = !fc.force_slow && !(fc.ablate & 64) && __all(!lit || zero_ok);
-                        const int cb = build_list2<STATS, TABLDS, true, false>(tab, fc, n, mylist, mykeys, b, lane, st_cull);
+                        const int cb = build_list2<STATS, TABLDS, true, false>(tab, fc, n, mylist, mykeys, myblks, b, lane, st_cull);
                         const int c = cb & 0x3fffffff;
                         if (may_skip && (cb & 0x40000000)) {
                             if (STATS == 1) hist[7] += 1;
@@ -1107,7 +1168,11 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
 
                 if (lit) {   // unlit lanes would add (0 * l.r) * r = +0
                     // b after `unshadowed` float+=double steps, then b *= max(normal.toL, 0)
+#if RT_EXP_NOLDSBTAB
                     float bsum = brightness_steps(unshadowed);
+#else
+                    float bsum = mybtab[unshadowed];
+#endif
                     const float a = dot3(normal, chain.toL);                    // kernel.cu:1541
                     bsum = bsum * (a > 0.f ? a : 0.f);
                     fr = fr + bsum * L.r * tr;                                  // kernel.cu:1673-1675
@@ -1143,8 +1208,12 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
         if (fc.packed && fc.resolve) {
             // mean over the frame's samples (x/1.0f is exact, so 1 spp is the
             // reference's rgbToInt(fr*254, fg*254, fb*254), kernel.cu:1682/1688)
-            const float mr = acc_r / fc.sample_total, mg = acc_g / fc.sample_total,
-                        mb = acc_b / fc.sample_total;
+            float mr = acc_r, mg = acc_g, mb = acc_b;
+            if (fc.sample_total != 1.f) {   // wave-uniform; three IEEE divisions saved at 1 spp
+                mr = acc_r / fc.sample_total;
+                mg = acc_g / fc.sample_total;
+                mb = acc_b / fc.sample_total;
+            }
             fc.packed[o] = rgb_to_int(f2i(mr * 254.f), f2i(mg * 254.f), f2i(mb * 254.f));
         }
     }
@@ -1281,10 +1350,12 @@ extern "C" hipError_t rt_dev_launch_trace(const RtFrameConsts *fc, const float4 
     const int n_pad = (fc->n_spheres + 63) & ~63;
     const size_t lds_bytes = (size_t)((table_in_lds ? n_pad : 0) + RT_WAVES_PER_WG * RT_LIST_CAP) * sizeof(float4) +
                              (size_t)RT_WAVES_PER_WG * RT_LIST_CAP * sizeof(int) +   // list positions (primary order)
+                             (size_t)RT_WAVES_PER_WG * 16 * sizeof(float) +          // brightness table per wave
+                             (size_t)RT_WAVES_PER_WG * 64 * sizeof(int) +            // marked blocks of a culling pass
                              (fc->n_boxes > 0 ? (size_t)RT_WAVES_PER_WG * RT_BOX_CAP * sizeof(int) : 0);
     const int band_h = fc->local_rows;
     const int th = 64 / tile_w;
-    const int wgx = (tile_w <= 16) ? 2 : 1;
+    const int wgx = (tile_w <= 16 && RT_WAVES_PER_WG >= 2) ? 2 : 1;
     const int wgy = RT_WAVES_PER_WG / wgx;
     dim3 grid((fc->width + tile_w * wgx - 1) / (tile_w * wgx), (band_h + th * wgy - 1) / (th * wgy));
     dim3 block(64 * RT_WAVES_PER_WG);
