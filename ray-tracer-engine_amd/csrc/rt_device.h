@@ -126,6 +126,14 @@ struct RtFrameConsts {
     const int *orig_idx;
     int n_blocks, pad_blocks_;
 
+    // per light, the table once more: ordered by 2-D Morton code of the centres' coordinates
+    // ACROSS the light's axis u = l.pos/|l.pos| and cut into blocks of RT_BLOCK, i.e. columns
+    // along u. Every shadow ray of a light runs within a few degrees of u, so a beam touches
+    // few columns. Two float4 per block: {point on the column axis, lateral radius} and
+    // {highest axial extent above that point, 3-D radius, -, -}. Null: use `sorted`/`blocks`.
+    const float *lsorted[RT_DEV_MAX_LIGHTS];
+    const float *lblocks[RT_DEV_MAX_LIGHTS];
+
     // outputs
     float *rgba;                // float4 per pixel, band-local, may be null
     uint32_t *packed;           // 0x00RRGGBB per pixel, band-local, may be null

@@ -132,6 +132,15 @@ struct rt_scene {
     int *d_tri_idx = nullptr;
     float *d_box_spheres = nullptr;
     int n_boxes = 0, n_tris = 0, mesh_has_normals = 0;
+    // per-light column blocks (see RtFrameConsts::lsorted): one allocation, rebuilt when the
+    // sphere list or a light's position changes
+    float4 *d_light_tabs = nullptr;
+    size_t cap_light_tabs = 0;           // float4 units
+    unsigned long long sphere_gen = 0;   // bumped whenever the mirrored sphere list changes
+    unsigned long long ltab_gen = ~0ull; // sphere_gen the light tables were built from
+    int ltab_n_lights = 0;
+    float ltab_axis[RT_MAX_LIGHTS][3];   // axis each table was built for
+    bool ltab_valid[RT_MAX_LIGHTS] = {};
 };
 
 // Largest table a workgroup can stage in LDS next to its lists, and the size up
@@ -171,6 +180,7 @@ extern "C" void rt_scene_destroy(rt_scene *s)
     if (s->d_boxes) (void)hipFree(s->d_boxes);
     if (s->d_tri_idx) (void)hipFree(s->d_tri_idx);
     if (s->d_box_spheres) (void)hipFree(s->d_box_spheres);
+    if (s->d_light_tabs) (void)hipFree(s->d_light_tabs);
     delete s;
 }
 
@@ -247,6 +257,157 @@ static void build_sorted_blocks(const float4 *tab, int n, float4 *sorted, float4
     }
 }
 
+// ---------------------------------------------------------------------------
+// Per-light column blocks. All shadow rays of a light run within a few degrees of
+// u = l.pos/|l.pos| (kernel.cu:1468 builds them relative to the world origin), so the table
+// is ordered by where the centres fall ACROSS u and cut into blocks of RT_BLOCK: columns
+// along u, which a beam along u touches far less often than the cubes of the 3-D order.
+// Block record, two float4: {cx, cy, cz, rho} and {s_hi, r3d, 0, 0} -- c the mean centre,
+// rho >= |(c_j - c) across u| + R_j, s_hi >= (c_j - c).u + R_j, r3d >= |c_j - c| + R_j for
+// every member j (R_j = sqrt of the table's squared effective radius), all rounded up.
+// ---------------------------------------------------------------------------
+static unsigned morton16(unsigned v)
+{
+    v &= 0xffffu;
+    v = (v | (v << 8)) & 0x00ff00ffu;
+    v = (v | (v << 4)) & 0x0f0f0f0fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+static void build_light_columns(const float4 *tab, int n, const float u_f[3], float4 *sorted, float4 *blocks)
+{
+    const int n_pad = (n + 63) & ~63;
+    const double u[3] = {u_f[0], u_f[1], u_f[2]};
+    // two directions across u
+    double e1[3] = {0, 0, 0};
+    {
+        const int k = (std::fabs(u[0]) <= std::fabs(u[1]) && std::fabs(u[0]) <= std::fabs(u[2])) ? 0
+                      : (std::fabs(u[1]) <= std::fabs(u[2]) ? 1 : 2);
+        double t[3] = {0, 0, 0};
+        t[k] = 1;
+        const double d = t[0] * u[0] + t[1] * u[1] + t[2] * u[2];
+        for (int i = 0; i < 3; ++i) e1[i] = t[i] - d * u[i];
+        const double l = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+        for (int i = 0; i < 3; ++i) e1[i] /= l;
+    }
+    const double e2[3] = {u[1] * e1[2] - u[2] * e1[1], u[2] * e1[0] - u[0] * e1[2], u[0] * e1[1] - u[1] * e1[0]};
+    std::vector<double> p1((size_t)n), p2((size_t)n);
+    double lo1 = INFINITY, hi1 = -INFINITY, lo2 = INFINITY, hi2 = -INFINITY;
+    std::vector<char> fin((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const double c[3] = {tab[i].x, tab[i].y, tab[i].z};
+        p1[i] = c[0] * e1[0] + c[1] * e1[1] + c[2] * e1[2];
+        p2[i] = c[0] * e2[0] + c[1] * e2[1] + c[2] * e2[2];
+        fin[i] = std::isfinite(p1[i]) && std::isfinite(p2[i]) && std::isfinite((double)tab[i].w);
+        if (fin[i]) {
+            lo1 = std::min(lo1, p1[i]); hi1 = std::max(hi1, p1[i]);
+            lo2 = std::min(lo2, p2[i]); hi2 = std::max(hi2, p2[i]);
+        }
+    }
+    std::vector<std::pair<unsigned long long, int>> keys((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        unsigned long long key = ~0ull;   // non-finite entries go last (their blocks are unbounded)
+        if (fin[i]) {
+            const double s1 = hi1 - lo1, s2 = hi2 - lo2;
+            const unsigned q1 = (unsigned)std::min(65535.0, std::max(0.0, s1 > 0 ? (p1[i] - lo1) / s1 * 65535.0 : 0.0));
+            const unsigned q2 = (unsigned)std::min(65535.0, std::max(0.0, s2 > 0 ? (p2[i] - lo2) / s2 * 65535.0 : 0.0));
+            key = morton16(q1) | ((unsigned long long)morton16(q2) << 1);
+        }
+        keys[i] = {key, i};
+    }
+    std::sort(keys.begin(), keys.end());
+    for (int i = 0; i < n_pad; ++i) sorted[i] = i < n ? tab[keys[i].second] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < n_pad / RT_BLOCK; ++b) {
+        const int i0 = b * RT_BLOCK, i1 = std::min(n, i0 + RT_BLOCK);
+        if (i0 >= n) {   // padding block: nothing in it, never examined
+            blocks[2 * b] = make_float4(0.f, 0.f, 0.f, -1.f);
+            blocks[2 * b + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
+        double cx = 0, cy = 0, cz = 0;
+        for (int i = i0; i < i1; ++i) { cx += sorted[i].x; cy += sorted[i].y; cz += sorted[i].z; }
+        const double inv = 1.0 / std::max(1, i1 - i0);
+        // the bounds below are taken around the ROUNDED centre the device will use
+        const float cf[3] = {(float)(cx * inv), (float)(cy * inv), (float)(cz * inv)};
+        double rho = 0, s_hi = -INFINITY, r3d = 0;
+        bool bad = !(std::isfinite(cf[0]) && std::isfinite(cf[1]) && std::isfinite(cf[2]));
+        for (int i = i0; i < i1 && !bad; ++i) {
+            const double d[3] = {sorted[i].x - (double)cf[0], sorted[i].y - (double)cf[1], sorted[i].z - (double)cf[2]};
+            const double w = sorted[i].w;
+            if (!(w == w) || !std::isfinite(d[0] + d[1] + d[2]) || !std::isfinite(w)) { bad = true; break; }
+            const double R = std::sqrt(std::max(0.0, w));
+            const double ax = d[0] * u[0] + d[1] * u[1] + d[2] * u[2];
+            const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+            const double lat = std::sqrt(std::max(0.0, dd - ax * ax));
+            rho = std::max(rho, lat + R);
+            s_hi = std::max(s_hi, ax + R);
+            r3d = std::max(r3d, std::sqrt(dd) + R);
+        }
+        if (bad) {   // always examined
+            blocks[2 * b] = make_float4(0.f, 0.f, 0.f, INFINITY);
+            blocks[2 * b + 1] = make_float4(INFINITY, INFINITY, 0.f, 0.f);
+            continue;
+        }
+        // rounded up; |u| differs from 1 by a few 1e-8, which the factors cover as well
+        blocks[2 * b] = make_float4(cf[0], cf[1], cf[2], (float)(rho * 1.001 + 1e-3));
+        blocks[2 * b + 1] = make_float4((float)(s_hi + std::fabs(s_hi) * 1e-3 + 1e-3), (float)(r3d * 1.001 + 1e-3), 0.f, 0.f);
+    }
+}
+
+// Bring the per-light tables up to date with the mirrored sphere list and the lights'
+// positions. Not inside a stream capture (rt_graph_capture calls it first).
+int rt_scene_prepare_lights(rt_scene *s, hipStream_t stream)
+{
+    const int n = s->n_spheres;
+    const int n_pad = (n + 63) & ~63, nb = n_pad / RT_BLOCK;
+    const bool want = n >= 64 && s->h_prev.size() == (size_t)n && !getenv("RT_NO_LIGHT_COLUMNS");
+    if (!want) {
+        for (int i = 0; i < RT_MAX_LIGHTS; ++i) s->ltab_valid[i] = false;
+        s->ltab_gen = ~0ull;
+        return RT_OK;
+    }
+    const size_t per_light = (size_t)n_pad + 2 * (size_t)nb;   // float4 units
+    float axis[RT_MAX_LIGHTS][3];
+    bool usable[RT_MAX_LIGHTS];
+    bool same = (s->ltab_gen == s->sphere_gen) && (s->ltab_n_lights == s->n_lights);
+    for (int i = 0; i < s->n_lights; ++i) {
+        const rt_light &l = s->lights[i];
+        const float len = std::sqrt(l.pos.x * l.pos.x + l.pos.y * l.pos.y + l.pos.z * l.pos.z);   // as rt_build_frame_consts
+        usable[i] = len > 0 && std::isfinite(len);
+        axis[i][0] = usable[i] ? l.pos.x / len : 0.f;
+        axis[i][1] = usable[i] ? l.pos.y / len : 0.f;
+        axis[i][2] = usable[i] ? l.pos.z / len : 0.f;
+        usable[i] = usable[i] && std::isfinite(axis[i][0]) && std::isfinite(axis[i][1]) && std::isfinite(axis[i][2]);
+        same = same && (usable[i] == s->ltab_valid[i]) &&
+               (!usable[i] || memcmp(axis[i], s->ltab_axis[i], sizeof axis[i]) == 0);
+    }
+    if (same) return RT_OK;
+    const size_t total = per_light * (size_t)std::max(1, s->n_lights);
+    if (total > s->cap_light_tabs) {
+        if (s->d_light_tabs) RT_HIP(hipFree(s->d_light_tabs));
+        s->d_light_tabs = nullptr;
+        s->cap_light_tabs = 0;
+        RT_HIP(hipMalloc((void **)&s->d_light_tabs, sizeof(float4) * total));
+        s->cap_light_tabs = total;
+    }
+    std::vector<float4> h(total);
+    for (int i = 0; i < s->n_lights; ++i) {
+        s->ltab_valid[i] = usable[i];
+        memcpy(s->ltab_axis[i], axis[i], sizeof axis[i]);
+        if (usable[i])
+            build_light_columns(s->h_prev.data(), n, axis[i], h.data() + per_light * i, h.data() + per_light * i + n_pad);
+    }
+    for (int i = s->n_lights; i < RT_MAX_LIGHTS; ++i) s->ltab_valid[i] = false;
+    // pageable source: the copy has left `h` when the call returns
+    RT_HIP(hipMemcpyAsync(s->d_light_tabs, h.data(), sizeof(float4) * total, hipMemcpyHostToDevice, stream));
+    RT_HIP(hipStreamSynchronize(stream));   // rare (scene or light change): `h` goes out of scope
+    s->ltab_gen = s->sphere_gen;
+    s->ltab_n_lights = s->n_lights;
+    return RT_OK;
+}
+
 int rt_scene_set_spheres_async(rt_scene *s, const rt_sphere *host_spheres, int n, hipStream_t stream)
 {
     if (!s || n < 0 || (n > 0 && !host_spheres)) {
@@ -292,8 +453,10 @@ int rt_scene_set_spheres_async(rt_scene *s, const rt_sphere *host_spheres, int n
         RT_HIP(hipEventRecord(s->stage_done, stream));
         s->stage_busy = true;
         s->h_prev.swap(packed);
+        s->sphere_gen++;
     } else {
         s->h_prev.clear();
+        s->sphere_gen++;
     }
     s->n_blocks = nb;
     s->n_spheres = n;
@@ -658,6 +821,13 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
         fc->blocks = base ? reinterpret_cast<const float *>(base + s->n_spheres + n_pad) : nullptr;
         fc->orig_idx = base ? reinterpret_cast<const int *>(base + s->n_spheres + n_pad + s->n_blocks) : nullptr;
         fc->n_blocks = s->n_blocks;
+        const size_t per_light = (size_t)n_pad + 2 * (size_t)s->n_blocks;
+        const bool current = s->d_light_tabs && s->ltab_gen == s->sphere_gen && s->ltab_n_lights == s->n_lights;
+        for (int i = 0; i < RT_DEV_MAX_LIGHTS; ++i) {
+            const bool on = current && i < s->n_lights && s->ltab_valid[i];
+            fc->lsorted[i] = on ? reinterpret_cast<const float *>(s->d_light_tabs + per_light * i) : nullptr;
+            fc->lblocks[i] = on ? reinterpret_cast<const float *>(s->d_light_tabs + per_light * i + n_pad) : nullptr;
+        }
     }
     fc->tris = s->d_tris;
     fc->boxes = s->d_boxes;
@@ -685,7 +855,16 @@ static int tile_from_opts(const rt_launch_opts &o, int *tile)
 extern "C" int rt_scene_render(rt_scene *s, const rt_frame_desc *fd, void *stream)
 {
     RtFrameConsts fc;
-    int rc = rt_build_frame_consts(s, fd, &fc);
+    int rc = RT_OK;
+    if (s && fd && fd->opts.cull != 0) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream) (void)hipStreamIsCapturing((hipStream_t)stream, &cs);
+        if (cs == hipStreamCaptureStatusNone) {   // a capture re-uses what rt_graph_capture prepared
+            rc = rt_scene_prepare_lights(s, (hipStream_t)stream);
+            if (rc != RT_OK) return rc;
+        }
+    }
+    rc = rt_build_frame_consts(s, fd, &fc);
     if (rc != RT_OK) return rc;
     int tile = 8;
     rc = tile_from_opts(fd->opts, &tile);

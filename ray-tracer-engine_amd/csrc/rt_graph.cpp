@@ -46,6 +46,11 @@ static int record_frame(rt_frame_graph *g, hipStream_t stream)
 
 static int capture(rt_frame_graph *g, hipStream_t stream, hipGraph_t *out)
 {
+    {   // per-light tables are (re)built outside the capture; the captured launches only read them
+        const int prc = rt_scene_prepare_lights(g->scene, stream);
+        if (prc != RT_OK) return prc;
+        RT_HIP(hipStreamSynchronize(stream));
+    }
     RT_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
     const int rc = record_frame(g, stream);
     hipGraph_t graph = nullptr;

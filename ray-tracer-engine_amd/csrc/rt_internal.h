@@ -18,3 +18,4 @@ int rt_hip_fail(hipError_t e, const char *expr, const char *file, int line);
 struct rt_scene;
 int rt_scene_set_spheres_async(rt_scene *s, const rt_sphere *host_spheres, int n, hipStream_t stream);
 int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameConsts *fc);
+int rt_scene_prepare_lights(rt_scene *s, hipStream_t stream);

@@ -33,9 +33,6 @@
 
 namespace {
 
-#ifndef RT_EXP_NOLDSBTAB
-#define RT_EXP_NOLDSBTAB 0
-#endif
 struct V3 {
     float x, y, z;
 };
@@ -156,6 +153,11 @@ __device__ __forceinline__ float brightness_steps(int n)
     b = n >= 10 ? 0x1.000002p+0f : b;
     return b;
 }
+
+// The same eleven values for per-lane lookups (copied into LDS once per wave).
+__device__ const float kBrightnessSteps[16] = {0x0.0p+0f,      0x1.99999ap-4f, 0x1.99999ap-3f, 0x1.333334p-2f,
+                                               0x1.99999ap-2f, 0x1.000000p-1f, 0x1.333334p-1f, 0x1.666668p-1f,
+                                               0x1.99999cp-1f, 0x1.ccccd0p-1f, 0x1.000002p+0f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
 // rgbToInt, kernel.cu:547-556
 __device__ __forceinline__ unsigned rgb_to_int(int r, int g, int b)
@@ -335,6 +337,25 @@ __device__ __forceinline__ bool beam_keeps_block(const Beam &b, float4 blk)
     return !(reach < 0.f) && !(d2 > rad * rad * 1.0005f);   // NaN / inf bounds keep the block
 }
 
+// A column block of a light's table (RtFrameConsts::lsorted/lblocks): blkA = {point c on the
+// column's axis, lateral radius rho}, blkB = {s_hi, r3d, -, -}. A member j passes
+// beam_member_test() only if its block passes this test: its axial coordinate plus radius is
+// at most (c - a).u + s_hi, its centre lies within rho - R_j of the column's axis, and its
+// padding sqrt(4e-5 |v_j|^2 + 1e-3) <= 6.4e-3 |v_j| + 0.032 with |v_j| <= |c - a| + r3d.
+// Only valid for beams whose axis is the light's u (all shadow beams are).
+__device__ __forceinline__ bool beam_keeps_column(const Beam &b, float4 blkA, float4 blkB)
+{
+    const float vx = blkA.x - b.ax, vy = blkA.y - b.ay, vz = blkA.z - b.az;
+    const float vv = __builtin_fmaf(vx, vx, __builtin_fmaf(vy, vy, vz * vz));
+    const float sa = __builtin_fmaf(vx, b.ux, __builtin_fmaf(vy, b.uy, vz * b.uz));
+    const float d2 = __builtin_fmaxf(__builtin_fmaf(-sa, sa, vv), 0.f);
+    const float dist = __builtin_amdgcn_sqrtf(vv) * 1.0001f;
+    const float pad = __builtin_fmaf(6.5e-3f, dist + blkB.y, 0.04f);
+    const float reach = sa + blkB.x + pad - b.smin;
+    const float rad = __builtin_fmaf(b.k, __builtin_fmaxf(reach, 0.f), b.r0) + blkA.w + pad;
+    return !(reach < 0.f) & !(d2 > rad * rad * 1.001f);   // NaN / inf bounds keep the block
+}
+
 // The sphere table is either the workgroup's LDS copy (TABLDS, up to a few
 // thousand spheres) or read straight from global memory (any N; coalesced 16 B
 // per lane, L2-resident), in which case LDS only holds the survivor lists.
@@ -412,12 +433,16 @@ __device__ __forceinline__ bool beam_member_test(const Beam &b, float4 s, bool e
 // that the first index still wins ties (kernel.cu:1335). Returns the survivor count
 // (with OCCL, bit 30 flags "one sphere occludes the whole beam"); a count above
 // RT_LIST_CAP tells the caller to walk the whole table instead.
-template <int STATS, bool TABLDS, bool OCCL, bool ORDERED>
+// With COLUMNS the blocks are a light's columns (csorted/cblocks, read from global memory)
+// instead of the cubes of the 3-D order.
+template <int STATS, bool TABLDS, bool OCCL, bool ORDERED, bool COLUMNS = false>
 __device__ __forceinline__ int build_list2(const float4 *tab, const RtFrameConsts &fc, int n, float4 *list, int *keys,
-                                           int *blist, const Beam &b, int lane, unsigned long long &n_cull)
+                                           int *blist, const Beam &b, int lane, unsigned long long &n_cull,
+                                           const float4 *__restrict__ csorted = nullptr,
+                                           const float4 *__restrict__ cblocks = nullptr)
 {
-    const float4 *__restrict__ gsorted = reinterpret_cast<const float4 *>(fc.sorted);
-    const float4 *__restrict__ gblocks = reinterpret_cast<const float4 *>(fc.blocks);
+    const float4 *__restrict__ gsorted = COLUMNS ? csorted : reinterpret_cast<const float4 *>(fc.sorted);
+    const float4 *__restrict__ gblocks = COLUMNS ? cblocks : reinterpret_cast<const float4 *>(fc.blocks);
     const int nb = fc.n_blocks;
     int count = 0;
     bool blk = false;
@@ -425,8 +450,15 @@ __device__ __forceinline__ int build_list2(const float4 *tab, const RtFrameConst
     const int grp = lane / RT_BLOCK, sub = lane % RT_BLOCK;
     for (int bbase = 0; bbase < nb; bbase += 64) {
         const int bi = bbase + lane;
-        const float4 bb = gblocks[bi < nb ? bi : nb - 1];
-        const bool kb = (bi < nb) && (bb.w >= 0.f || bb.w != bb.w) && beam_keeps_block(b, bb);   // w < 0: padding block
+        const int bc = bi < nb ? bi : nb - 1;
+        bool kb;
+        if (COLUMNS) {
+            const float4 ba = gblocks[2 * bc], bbx = gblocks[2 * bc + 1];
+            kb = (bi < nb) & (ba.w >= 0.f || ba.w != ba.w) & beam_keeps_column(b, ba, bbx);
+        } else {
+            const float4 bb = gblocks[bc];
+            kb = (bi < nb) && (bb.w >= 0.f || bb.w != bb.w) && beam_keeps_block(b, bb);   // w < 0: padding block
+        }
         const unsigned long long bm = __ballot(kb);
         if (STATS == 1) n_cull += 64;
         // the marked blocks, compacted into the wave's block list; then G of them per step,
@@ -439,7 +471,7 @@ __device__ __forceinline__ int build_list2(const float4 *tab, const RtFrameConst
             const int nslot = t + G + grp;
             const int nxt = (nslot < marked) ? blist[nslot] : -1;
             const int i = (cur < 0 ? 0 : cur) * RT_BLOCK + sub;   // inside the padded table
-            const float4 s = table_at<TABLDS>(tab, gsorted, i);
+            const float4 s = table_at<TABLDS && !COLUMNS>(tab, gsorted, i);
             const bool keep = beam_member_test<OCCL>(b, s, (cur >= 0) & (i < n), blk);
             const unsigned long long m = __ballot(keep);
             const int pos = count + lane_prefix(m);
@@ -644,7 +676,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                   RT_WAVES_PER_WG * (RT_LIST_CAP + 16) + wave * 64;
     int *myboxes = reinterpret_cast<int *>(lds + (TABLDS ? n_pad : 0) + RT_WAVES_PER_WG * RT_LIST_CAP) +
                    RT_WAVES_PER_WG * (RT_LIST_CAP + 16 + 64) + wave * RT_BOX_CAP;
-    if (lane < 16) mybtab[lane] = brightness_steps(lane);
+    if (lane < 16) mybtab[lane] = kBrightnessSteps[lane];   // same values as brightness_steps()
     wave_lds_sync();
 
     const int tile_x = (blockIdx.x * WGX + (wave % WGX)) * TW;
@@ -1045,7 +1077,12 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
                         // every lit lane: unshadowed = 0, b = 0, and the light adds exactly
                         // nothing -- the sample construction and the tests are skipped.
                         const bool may_skip = !fc.force_slow && !(fc.ablate & 64) && __all(!lit || zero_ok);
-                        const int cb = build_list2<STATS, TABLDS, true, false>(tab, fc, n, mylist, mykeys, myblks, b, lane, st_cull);
+                        const float4 *lsorted = reinterpret_cast<const float4 *>(fc.lsorted[li]);
+                        const int cb = lsorted ? build_list2<STATS, TABLDS, true, false, true>(
+                                                     tab, fc, n, mylist, mykeys, myblks, b, lane, st_cull, lsorted,
+                                                     reinterpret_cast<const float4 *>(fc.lblocks[li]))
+                                               : build_list2<STATS, TABLDS, true, false>(tab, fc, n, mylist, mykeys, myblks, b,
+                                                                                         lane, st_cull);
                         const int c = cb & 0x3fffffff;
                         if (may_skip && (cb & 0x40000000)) {
                             if (STATS == 1) hist[7] += 1;
@@ -1168,11 +1205,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
 
                 if (lit) {   // unlit lanes would add (0 * l.r) * r = +0
                     // b after `unshadowed` float+=double steps, then b *= max(normal.toL, 0)
-#if RT_EXP_NOLDSBTAB
-                    float bsum = brightness_steps(unshadowed);
-#else
                     float bsum = mybtab[unshadowed];
-#endif
                     const float a = dot3(normal, chain.toL);                    // kernel.cu:1541
                     bsum = bsum * (a > 0.f ? a : 0.f);
                     fr = fr + bsum * L.r * tr;                                  // kernel.cu:1673-1675
