@@ -247,7 +247,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C3: {w}x{h}, {args.spheres} spheres (MSVC rand() replay seed {args.seed}), "
-                                   f"{args.spp} spp, 3 lights x 10 shadow samples, LDS sphere-tile staging on",
+                                   f"{args.spp} spp, 3 lights x 10 shadow samples, LDS sphere-tile staging on "
+                                   f"(per-tile survivor lists; RT_TABLE_LDS=1 stages the whole table instead)",
                        "cull": not args.no_cull, "tile": args.tile or 8,
                        "parallelism": f"{BLOCK}-row blocks round-robin x{world} + 1 RCCL gather per frame "
                                       f"(overlapped with the next frame's kernel)" if world > 1 else "single GPU",

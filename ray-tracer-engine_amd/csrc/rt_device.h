@@ -22,16 +22,12 @@
                                // that add 0.6 GB of scratch writes per frame.
 #endif
 #ifndef RT_WAVES_PER_WG
-#define RT_WAVES_PER_WG 4         // wave tiles per workgroup (1, 2 or 4)
+#define RT_WAVES_PER_WG 4         // wave tiles per workgroup when the table is staged in LDS (1, 2 or 4)
 #endif
 #ifndef RT_BLOCK
 #define RT_BLOCK 16             // spheres per block of the Morton-ordered table (divides 64)
 #endif
 #define RT_BOX_CAP 128          // leaf-box list capacity per wave (ints in LDS, mesh scenes only)
-#ifndef RT_TABLE_LDS_MAX
-#define RT_TABLE_LDS_MAX 1024   // sphere tables up to this size are staged in LDS (16 KiB); measured at
-                                // 3840x2160: N=1024 LDS 1.48 ms vs global 1.50 ms, N=4096 LDS 4.49 vs global 2.64
-#endif
 
 // Smallest binary32 >= 0.0001 (binary64): `t >= 0.0001` (kernel.cu:342) compares
 // the widened float with the double literal, which is equivalent to a float

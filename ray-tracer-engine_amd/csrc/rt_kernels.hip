@@ -643,11 +643,15 @@ __device__ __forceinline__ void shadow_test(const RayK &sr, float4 s, bool &shad
 // STATS: 0 = product kernel, 1 = work counters, 2 = per-phase cycle stamps
 // (s_memtime; a diagnostic build whose run time is never quoted).
 template <int TW, bool CULL, int STATS, bool TABLDS, bool MESH = false>
-__global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void rt_trace_tiles(const RtFrameConsts fc,
+__global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_PER_SIMD) void rt_trace_tiles(const RtFrameConsts fc,
                                                                      const float4 *__restrict__ spheres)
 {
     constexpr int TH = 64 / TW;
-    constexpr int WGX = (TW <= 16 && RT_WAVES_PER_WG >= 2) ? 2 : 1;   // wave tiles per workgroup in x
+    // Waves per workgroup: RT_WAVES_PER_WG share one staged table (TABLDS); with the table left
+    // in global memory nothing is shared, and one-wave workgroups fill the SIMDs best
+    // (0.68 vs 0.71 ms at C3) and need no barrier.
+    constexpr int WPW = TABLDS ? RT_WAVES_PER_WG : 1;
+    constexpr int WGX = (TW <= 16 && WPW >= 2) ? 2 : 1;   // wave tiles per workgroup in x
     extern __shared__ float4 lds[];
 
     const int tid = threadIdx.x;
@@ -662,20 +666,20 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
         // the culling kernels stage the Morton-ordered copy (whole blocks, n_pad entries);
         // the brute-force kernels stage the list as it is
         const float4 *src = CULL ? reinterpret_cast<const float4 *>(fc.sorted) : spheres;
-        for (int i = tid; i < (CULL ? n_pad : n); i += 64 * RT_WAVES_PER_WG) tab[i] = src[i];
+        for (int i = tid; i < (CULL ? n_pad : n); i += 64 * WPW) tab[i] = src[i];
         __syncthreads();
     }
     float4 *mylist = lds + (TABLDS ? n_pad : 0) + wave * RT_LIST_CAP;
-    int *mykeys = reinterpret_cast<int *>(lds + (TABLDS ? n_pad : 0) + RT_WAVES_PER_WG * RT_LIST_CAP) + wave * RT_LIST_CAP;
+    int *mykeys = reinterpret_cast<int *>(lds + (TABLDS ? n_pad : 0) + WPW * RT_LIST_CAP) + wave * RT_LIST_CAP;
     // b after n float+=double steps of 0.1 (brightness_steps), one 16-entry copy per wave: a
     // per-lane n then costs one LDS read instead of a ten-deep select chain per light
-    float *mybtab = reinterpret_cast<float *>(lds + (TABLDS ? n_pad : 0) + RT_WAVES_PER_WG * RT_LIST_CAP) +
-                    RT_WAVES_PER_WG * RT_LIST_CAP + wave * 16;
+    float *mybtab = reinterpret_cast<float *>(lds + (TABLDS ? n_pad : 0) + WPW * RT_LIST_CAP) +
+                    WPW * RT_LIST_CAP + wave * 16;
     // marked blocks of one culling pass (at most 64 at a time)
-    int *myblks = reinterpret_cast<int *>(lds + (TABLDS ? n_pad : 0) + RT_WAVES_PER_WG * RT_LIST_CAP) +
-                  RT_WAVES_PER_WG * (RT_LIST_CAP + 16) + wave * 64;
-    int *myboxes = reinterpret_cast<int *>(lds + (TABLDS ? n_pad : 0) + RT_WAVES_PER_WG * RT_LIST_CAP) +
-                   RT_WAVES_PER_WG * (RT_LIST_CAP + 16 + 64) + wave * RT_BOX_CAP;
+    int *myblks = reinterpret_cast<int *>(lds + (TABLDS ? n_pad : 0) + WPW * RT_LIST_CAP) +
+                  WPW * (RT_LIST_CAP + 16) + wave * 64;
+    int *myboxes = reinterpret_cast<int *>(lds + (TABLDS ? n_pad : 0) + WPW * RT_LIST_CAP) +
+                   WPW * (RT_LIST_CAP + 16 + 64) + wave * RT_BOX_CAP;
     if (lane < 16) mybtab[lane] = kBrightnessSteps[lane];   // same values as brightness_steps()
     wave_lds_sync();
 
@@ -683,7 +687,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_WG, RT_MIN_WAVES_PER_SIMD) void r
     // local row -> global row: a contiguous band, or row blocks dealt round-robin
     // to the ranks of a multi-GPU frame (il_rows is a multiple of the tile rows a
     // workgroup covers, so a tile never straddles two blocks)
-    const int ly = (blockIdx.y * (RT_WAVES_PER_WG / WGX) + (wave / WGX)) * TH + (lane / TW);
+    const int ly = (blockIdx.y * (WPW / WGX) + (wave / WGX)) * TH + (lane / TW);
     const int px = tile_x + (lane % TW);
     const int py = (fc.il_count > 1) ? ((ly / fc.il_rows) * fc.il_count + fc.il_index) * fc.il_rows + (ly % fc.il_rows)
                                      : fc.y0 + ly;
@@ -1381,17 +1385,18 @@ extern "C" hipError_t rt_dev_launch_trace(const RtFrameConsts *fc, const float4 
 {
     if (fc->n_boxes > 0 && (tile_w != 8 || stats != 0)) return hipErrorNotSupported;   // mesh scenes: default tile only
     const int n_pad = (fc->n_spheres + 63) & ~63;
-    const size_t lds_bytes = (size_t)((table_in_lds ? n_pad : 0) + RT_WAVES_PER_WG * RT_LIST_CAP) * sizeof(float4) +
-                             (size_t)RT_WAVES_PER_WG * RT_LIST_CAP * sizeof(int) +   // list positions (primary order)
-                             (size_t)RT_WAVES_PER_WG * 16 * sizeof(float) +          // brightness table per wave
-                             (size_t)RT_WAVES_PER_WG * 64 * sizeof(int) +            // marked blocks of a culling pass
-                             (fc->n_boxes > 0 ? (size_t)RT_WAVES_PER_WG * RT_BOX_CAP * sizeof(int) : 0);
+    const int wpw = table_in_lds ? RT_WAVES_PER_WG : 1;   // as WPW in the kernel
+    const size_t lds_bytes = (size_t)((table_in_lds ? n_pad : 0) + wpw * RT_LIST_CAP) * sizeof(float4) +
+                             (size_t)wpw * RT_LIST_CAP * sizeof(int) +   // list positions (primary order)
+                             (size_t)wpw * 16 * sizeof(float) +          // brightness table per wave
+                             (size_t)wpw * 64 * sizeof(int) +            // marked blocks of a culling pass
+                             (fc->n_boxes > 0 ? (size_t)wpw * RT_BOX_CAP * sizeof(int) : 0);
     const int band_h = fc->local_rows;
     const int th = 64 / tile_w;
-    const int wgx = (tile_w <= 16 && RT_WAVES_PER_WG >= 2) ? 2 : 1;
-    const int wgy = RT_WAVES_PER_WG / wgx;
+    const int wgx = (tile_w <= 16 && wpw >= 2) ? 2 : 1;
+    const int wgy = wpw / wgx;
     dim3 grid((fc->width + tile_w * wgx - 1) / (tile_w * wgx), (band_h + th * wgy - 1) / (th * wgy));
-    dim3 block(64 * RT_WAVES_PER_WG);
+    dim3 block(64 * wpw);
     {
         const hipError_t pe = rt_dev_prepare();
         if (pe != hipSuccess) return pe;

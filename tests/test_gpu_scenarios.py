@@ -164,9 +164,9 @@ def test_random_seeds_and_counts(rt, gpu, n, seed):
 
 
 def test_table_in_global_memory_matches_lds_staging(rt, gpu, monkeypatch):
-    """Above RT_TABLE_LDS_MAX spheres the kernel reads the table from global
-    memory instead of staging it in LDS; forcing that mode on small scenes must
-    not change a bit."""
+    """By default the kernel reads the table from global memory and keeps only
+    the tiles' survivor lists in LDS; RT_TABLE_LDS=1 stages the whole table per
+    workgroup instead. Neither mode may change a bit."""
     import torch
     from scenes import Inputs
     for n in (100, 1024):
@@ -182,9 +182,9 @@ def test_table_in_global_memory_matches_lds_staging(rt, gpu, monkeypatch):
     monkeypatch.delenv("RT_TABLE_LDS")
 
 
-def test_large_sphere_counts(rt, gpu):
-    """Maximum sizes: 9000 spheres still fit the LDS-staged kernel when forced,
-    20000 use the global-memory table; both equal the brute-force loops. The
+def test_large_sphere_counts(rt, gpu, monkeypatch):
+    """Maximum sizes: 9000 and 20000 spheres (global-memory table; 9000 also with
+    the table staged in LDS, which it still fits) equal the brute-force loops. The
     oracle agrees on a tiny frame."""
     import torch
     from scenes import Inputs
@@ -195,6 +195,12 @@ def test_large_sphere_counts(rt, gpu):
         b = sc.render(24, 16, cull=False)
         torch.cuda.synchronize()
         assert torch.equal(a["rgba"], b["rgba"]) and torch.equal(a["packed"], b["packed"])
+        if n == 9000:
+            monkeypatch.setenv("RT_TABLE_LDS", "1")
+            c = sc.render(24, 16, cull=True)
+            torch.cuda.synchronize()
+            monkeypatch.delenv("RT_TABLE_LDS")
+            assert torch.equal(a["rgba"], c["rgba"]) and torch.equal(a["packed"], c["packed"])
     Scn.check(_as_scn(rt, Inputs(rt, 20000, 12)), 16, 8)
     s = rt.Scene()
     n = (1 << 22) + 1
