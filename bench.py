@@ -57,6 +57,9 @@ def parse():
                     help="nccl (= RCCL over xGMI) for real runs; gloo + --share-gpu only to rehearse the "
                          "N>1 code path on a box with fewer GPUs than ranks")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2],
+                    help="consecutive frames alternate between this many HIP streams, each with its own "
+                         "framebuffers (2: one frame's last waves overlap the next frame's first)")
     return ap.parse_args()
 
 
@@ -98,6 +101,31 @@ def cpu_baseline(rt, scene, args, gpu_rgba, gpu_packed):
         "tests_per_ray": tests / rays,
         "gpu_vs_cpu_mismatched_pixels": mismatched if gpu_rgba is not None else None,
     }
+
+
+def valu_issue(args, world, ms_per_step):
+    """VALU instruction issue rate against the plain-op issue rate measured on this chip
+    (tools/ubench/valu_rate.hip: 1.05 ns per wave64 v_mul/v_add per SIMD, profiles/r01_valu_issue_rates.txt).
+    Instructions per wave come from the committed PMC pass (SQ_INSTS_VALU), the time is this run's."""
+    if world != 1 or (args.width, args.height, args.spheres, args.spp) != (3840, 2160, 1024, 1) or args.no_cull:
+        return {}
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        per_wave = d["derived"]["valu_insts_per_wave"]
+        waves = d["pmc_avg_per_dispatch"]["SQ_WAVES"]
+    except Exception:
+        return {}
+    simds = 256 * 4
+    rate = per_wave * waves / simds / (ms_per_step * 1e-3)          # VALU instructions per second per SIMD
+    peak = 1.0 / 1.05e-9
+    return {"valu_insts_per_wave_pmc": per_wave, "valu_issue_rate_per_simd_Ginst_s": rate / 1e9,
+            "valu_issue_peak_per_simd_Ginst_s": peak / 1e9, "valu_issue_frac": rate / peak,
+            "valu_issue_note": "plain fp32 ops issue at 0.95 G/s per SIMD; compares, selects, binary64, division "
+                               "helpers take 1.7x and transcendentals 3.3x that slot, so the pipe is busier than "
+                               "this fraction (DESIGN.md section 4, roofline)"}
 
 
 def pmc_traffic(args, world):
@@ -156,45 +184,49 @@ def main():
         rows = max_rows = h
         interleave = None
 
-    # outputs resident in HBM: float4 linear colour + packed words, band-local.
-    # Two packed buffers so that frame i's gather overlaps frame i+1's kernel.
-    rgba = torch.empty((rows, w, 4), dtype=torch.float32, device="cuda")
+    # outputs resident in HBM: float4 linear colour + packed words, band-local. Two sets:
+    # frames alternate between them (and between two streams when --frames-in-flight 2), so
+    # that frame i's last waves -- and, for N > 1, its gather -- overlap frame i+1's kernel.
+    nfl = args.frames_in_flight
+    rgba2 = [torch.empty((rows, w, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
     packed2 = [torch.zeros((max_rows, w), dtype=torch.int32, device="cuda") for _ in range(2)]
     roots = [rd.InterleavedGather(h, w, world, coll_dev, BLOCK) for _ in range(2)] if (world > 1 and rank == 0) else None
     gathered2 = [roots[0].views, roots[1].views] if roots else [None, None]
     frame = None
-    stream = torch.cuda.current_stream()
-    fds = [scene.frame_desc(w, h, pixels=p.data_ptr(), rgba=rgba.data_ptr(), y0=y0, y1=y1, spp=args.spp,
-                            cull=not args.no_cull, tile=args.tile, interleave=interleave) for p in packed2]
-    packed = packed2[0]
+    main_stream = torch.cuda.current_stream()
+    streams = [torch.cuda.Stream() for _ in range(2)] if nfl == 2 else [main_stream, main_stream]
+    fds = [scene.frame_desc(w, h, pixels=packed2[b].data_ptr(), rgba=rgba2[b].data_ptr(), y0=y0, y1=y1, spp=args.spp,
+                            cull=not args.no_cull, tile=args.tile, interleave=interleave) for b in range(2)]
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     pending = [None, None]
 
     def finish(b):
-        """Complete frame b's gather and, on the root, put the rows in place."""
+        """Complete frame b's gather and, on the root, put the rows in place (on b's stream)."""
         if pending[b] is not None:
-            pending[b].wait()
-            pending[b] = None
-            if rank == 0:
-                nonlocal frame
-                frame = roots[b].assemble()       # one index_select puts every row in place
+            with torch.cuda.stream(streams[b]):
+                pending[b].wait()
+                pending[b] = None
+                if rank == 0:
+                    nonlocal frame
+                    frame = roots[b].assemble()       # one index_select puts every row in place
 
     def step(k, i=None):
         b = k & 1
         if world > 1:
-            finish(b)                      # buffer b is free again
-        if i is not None:
-            ev[i][0].record(stream)
-        scene.render_raw(fds[b], stream.cuda_stream)
-        if i is not None:
-            ev[i][1].record(stream)
-        if world > 1:                      # the frame's single collective, asynchronous
-            src = packed2[b] if coll_dev == "cuda" else packed2[b].cpu()
-            if rank == 0:
-                pending[b] = dist.gather(src, gathered2[b], dst=0, async_op=True)
-            else:
-                pending[b] = dist.gather(src, None, dst=0, async_op=True)
+            finish(b)                      # buffer set b is free again
+        with torch.cuda.stream(streams[b]):
+            if i is not None:
+                ev[i][0].record(streams[b])
+            scene.render_raw(fds[b], streams[b].cuda_stream)
+            if i is not None:
+                ev[i][1].record(streams[b])
+            if world > 1:                  # the frame's single collective, asynchronous, ordered after b's kernel
+                src = packed2[b] if coll_dev == "cuda" else packed2[b].cpu()
+                if rank == 0:
+                    pending[b] = dist.gather(src, gathered2[b], dst=0, async_op=True)
+                else:
+                    pending[b] = dist.gather(src, None, dst=0, async_op=True)
 
     k = 0
     for _ in range(args.warmup):
@@ -217,6 +249,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     packed = packed2[(k - 1) & 1]
+    rgba = rgba2[(k - 1) & 1]
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=coll_dev)
@@ -239,7 +272,7 @@ def main():
         band_bytes = rows * w * (16 + 4) * 1.0      # algorithmic bytes of one launch (float4 + packed word per pixel)
         achieved = band_bytes / (kernel_ms * 1e-3) / 1e9
         slots = stats["wave_test_slots"] + stats["cull_tests"]     # lane slots issued for sphere/beam tests
-        valu_tflops = slots * FLOP_PER_TEST / (kernel_ms_max * 1e-3) / 1e12
+        valu_tflops = slots * FLOP_PER_TEST / (ms_per_step * 1e-3) / 1e12
         out = {
             "metric": "primary_Mrays_per_s", "value": value, "unit": "Mrays/s",
             "frames_per_s": 1e3 / ms_per_step,
@@ -252,17 +285,24 @@ def main():
                        "cull": not args.no_cull, "tile": args.tile or 8,
                        "parallelism": f"{BLOCK}-row blocks round-robin x{world} + 1 RCCL gather per frame "
                                       f"(overlapped with the next frame's kernel)" if world > 1 else "single GPU",
+                       "frames_in_flight": nfl,
                        "outputs": "float4 RGBA + packed 0x00RRGGBB in HBM"},
             "kernel_ms": kernel_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, world),
                          "algorithmic_bytes_per_launch": band_bytes,
-                         "note": "HBM is NOT the binding roof for this path (SURVEY.md F2); see roofline_valu"},
+                         "achieved_chip": nfl * achieved,
+                         "note": "HBM is NOT the binding roof for this path (SURVEY.md F2); see roofline_valu. "
+                                 + ("Two frames are in flight on two streams: a launch's duration (kernel_ms, HIP "
+                                    "events on its stream) spans two overlapped kernels, so the chip moves "
+                                    "achieved_chip = 2 x achieved; per-frame time is ms_per_step."
+                                    if nfl == 2 else "One frame in flight.")},
             "roofline_valu": {"bound": "valu_fp32", "achieved": valu_tflops, "peak": VALU_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": valu_tflops / VALU_PEAK_TFLOPS,
                               "executed_test_slots": slots,
-                              "note": "64-lane issue slots of sphere + beam tests x 17 flop / kernel time; "
-                                      "excludes ray setup and shading ALU work"},
+                              "note": "64-lane issue slots of sphere + beam tests x 17 flop / frame time; "
+                                      "excludes ray setup and shading ALU work (most of the instructions)",
+                              **valu_issue(args, world, ms_per_step)},
             "work": {"hit_fraction": stats["hit_pixels"] / rays, "primary_lane_tests_per_ray": stats["primary_tests"] / rays,
                      "shadow_lane_tests_per_ray": stats["shadow_tests"] / rays,
                      "cull_tests_per_ray": stats["cull_tests"] / rays,
@@ -276,7 +316,7 @@ def main():
             brute_tests = cb["tests_per_ray"] * rays
             out["cpu_baseline"] = cb
             out["work"]["brute_force_tests_per_ray"] = cb["tests_per_ray"]
-            out["work"]["algorithmic_rate_TFLOPs"] = brute_tests * FLOP_PER_TEST / (kernel_ms * 1e-3) / 1e12
+            out["work"]["algorithmic_rate_TFLOPs"] = brute_tests * FLOP_PER_TEST / (ms_per_step * 1e-3) / 1e12
             out["work"]["executed_over_brute_force"] = slots / brute_tests
         if world > 1:
             idx = torch.as_tensor(my_rows, device=frame.device)

@@ -35,7 +35,8 @@ STAT_NAMES = ("primary_tests", "shadow_tests", "cull_tests", "hit_pixels", "unsh
               "wave_test_slots", "list_entries", "list_overflows",
               "cyc_ray_setup", "cyc_primary_cull", "cyc_primary_tests", "cyc_shade_sky", "cyc_beam_bound",
               "cyc_shadow_cull", "cyc_sample_dirs", "cyc_shadow_tests",
-              "clusters", "r17", "r18", "r19", "r20", "r21", "r22", "r23")
+              "clusters", "waves_lt5us", "waves_lt10us", "waves_lt20us", "waves_lt40us", "waves_lt80us", "waves_lt160us",
+              "waves_ge160us")
 
 
 class RtError(RuntimeError):

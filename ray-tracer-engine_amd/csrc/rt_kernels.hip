@@ -701,8 +701,10 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
     unsigned long long hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = 0;
-    auto phase = [&](int k) {   // charge the cycles since the previous stamp to phase k
-        if (STATS == 2) {
+    const bool span_only = (fc.ablate & 512) != 0;   // no inner stamps: near-real wave durations
+    const unsigned long long rt_begin = (STATS == 2) ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz
+    auto phase = [&](int k, bool last = false) {   // charge the cycles since the previous stamp to phase k
+        if (STATS == 2 && (k < 0 || last || !span_only)) {
             __builtin_amdgcn_sched_barrier(0);
             const unsigned long long now = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): s_memtime returns through it
@@ -1255,10 +1257,21 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
         }
     }
 
-    phase(3);
+    phase(3, true);
     if (STATS == 2 && fc.stats) {
-        if (lane == 0)
-            for (int k = 0; k < 8; ++k) atomicAdd(&fc.stats[8 + k], ph[k]);
+        if (lane == 0) {
+            unsigned long long tot = 0;
+            for (int k = 0; k < 8; ++k) {
+                atomicAdd(&fc.stats[8 + k], ph[k]);
+                tot += ph[k];
+            }
+            // wave durations (constant 100 MHz clock), octaves: [<5, <10, <20, <40, <80, <160, >=160] us
+            const unsigned long long span = __builtin_amdgcn_s_memrealtime() - rt_begin;
+            int bin = 0;
+            while (bin < 6 && span >= (500ull << bin)) ++bin;
+            atomicAdd(&fc.stats[17 + bin], 1ull);
+            (void)tot;
+        }
     }
     if (STATS == 1 && fc.stats) {
         // per-lane counters were kept wave-uniform except hits/unshadowed
