@@ -1030,7 +1030,7 @@ struct DevBuf {
 
 extern "C" int rt_debug_math(int op, const float *a, const float *b, float *out, int n)
 {
-    if (n <= 0 || !a || !out || op < 0 || op > 3 || (op == 3 && !b)) return RT_ERR_INVALID;
+    if (n <= 0 || !a || !out || op < 0 || op > 5 || (op == 3 && !b)) return RT_ERR_INVALID;
     DevBuf<float> da, db, dout;
     int rc;
     if ((rc = da.alloc(n)) || (rc = db.alloc(n)) || (rc = dout.alloc(n))) return rc;

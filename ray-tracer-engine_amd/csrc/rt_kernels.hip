@@ -159,6 +159,19 @@ __device__ const float kBrightnessSteps[16] = {0x0.0p+0f,      0x1.99999ap-4f, 0
                                                0x1.99999ap-2f, 0x1.000000p-1f, 0x1.333334p-1f, 0x1.666668p-1f,
                                                0x1.99999cp-1f, 0x1.ccccd0p-1f, 0x1.000002p+0f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+// rtm::atan_eighth(0..8), for the same purpose (values checked against the function by
+// tests/test_gpu_parity.py through the math debug ops, which use the LDS copy as well).
+__device__ const double kAtanEighth[16] = {0x0.0p+0,
+                                           0x1.fd5ba9aac2f6ep-4,
+                                           0x1.f5b75f92c80ddp-3,
+                                           0x1.6f61941e4def1p-2,
+                                           0x1.dac670561bb4fp-2,
+                                           0x1.1e00babdefeb4p-1,
+                                           0x1.4978fa3269ee1p-1,
+                                           0x1.700a7c5784634p-1,
+                                           0x1.921fb54442d18p-1,
+                                           0, 0, 0, 0, 0, 0, 0};
+
 // rgbToInt, kernel.cu:547-556
 __device__ __forceinline__ unsigned rgb_to_int(int r, int g, int b)
 {
@@ -567,7 +580,8 @@ struct ShadowChain {
     // (kernel.cu:1465-1466). Once two more normalisations leave toL
     // bit-identical, every later iteration reproduces the same values, so the
     // block is skipped (70 % of lanes are stable after j = 0, 99.6 % after j = 1).
-    __device__ __forceinline__ V3 direction(const RtFrameConsts &fc, const RtLightDev &L, V3 start, int j)
+    __device__ __forceinline__ V3 direction(const RtFrameConsts &fc, const RtLightDev &L, V3 start, int j,
+                                            const double *atab = nullptr)
     {
         const V3 lpos{L.px, L.py, L.pz};
         if (!stable || fc.force_slow) {
@@ -584,7 +598,7 @@ struct ShadowChain {
             const V3 axis = normalise_inplace(ax0);
             // nAngle = acosf(dot(normalise(toL), (0,0,1))), kernel.cu:1466
             const V3 n2 = normalise_inplace(toL);
-            const float nAngle = rtm::acosf_rt((n2.x * 0.f + n2.y * 0.f) + n2.z * 1.f);
+            const float nAngle = rtm::acosf_rt((n2.x * 0.f + n2.y * 0.f) + n2.z * 1.f, atab);
             float sn, cs;
             rtm::sincosf_rt(nAngle, sn, cs);
             const float omc = 1.f - cs;
@@ -678,9 +692,15 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
     // marked blocks of one culling pass (at most 64 at a time)
     int *myblks = reinterpret_cast<int *>(lds + (TABLDS ? n_pad : 0) + WPW * RT_LIST_CAP) +
                   WPW * (RT_LIST_CAP + 16) + wave * 64;
+    // rtm::atan_eighth(0..8) for the binary64 arctangent (one LDS read instead of a select chain)
+    double *myatan = reinterpret_cast<double *>(reinterpret_cast<int *>(lds + (TABLDS ? n_pad : 0) + WPW * RT_LIST_CAP) +
+                                                WPW * (RT_LIST_CAP + 16 + 64)) + wave * 16;
     int *myboxes = reinterpret_cast<int *>(lds + (TABLDS ? n_pad : 0) + WPW * RT_LIST_CAP) +
-                   WPW * (RT_LIST_CAP + 16 + 64) + wave * RT_BOX_CAP;
-    if (lane < 16) mybtab[lane] = kBrightnessSteps[lane];   // same values as brightness_steps()
+                   WPW * (RT_LIST_CAP + 16 + 64 + 32) + wave * RT_BOX_CAP;
+    if (lane < 16) {
+        mybtab[lane] = kBrightnessSteps[lane];   // same values as brightness_steps()
+        myatan[lane] = kAtanEighth[lane];
+    }
     wave_lds_sync();
 
     const int tile_x = (blockIdx.x * WGX + (wave % WGX)) * TW;
@@ -877,8 +897,8 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
             const V3 hp{O.x + D.x * t, O.y + D.y * t, O.z + D.z * t};
             V3 nrm{hp.x - sk.x, hp.y - sk.y, hp.z - sk.z};
             normalise_inplace(nrm);
-            const int ix = f2i((1.f + rtm::atan2f_rt(nrm.z, nrm.x) / 3.1415f) * 0.5f * (float)fc.sky_w);
-            const int iy = f2i(rtm::acosf_rt(nrm.y) / 3.1415f * (float)fc.sky_h);
+            const int ix = f2i((1.f + rtm::atan2f_rt(nrm.z, nrm.x, myatan) / 3.1415f) * 0.5f * (float)fc.sky_w);
+            const int iy = f2i(rtm::acosf_rt(nrm.y, myatan) / 3.1415f * (float)fc.sky_h);
             int idx = iy * fc.sky_w + ix;
             const int last = fc.sky_w * fc.sky_h - 1;
             idx = idx < 0 ? 0 : (idx > last ? last : idx);   // documented clamp (reference is UB there)
@@ -917,8 +937,9 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                     tx = normal.x; ty = normal.y;
                 } else {
                     // the literals 1, 3.1415, 0.5 make these binary64 expressions
-                    tx = (float)((1.0 + (double)rtm::atan2f_rt(normal.z, normal.x) / 3.1415) * 0.5);
-                    ty = (float)((double)rtm::acosf_rt(normal.y) / 3.1415);
+                    // kernel.cu:1402-1403; "/ 3.1415" in binary64 through div_by_3p1415 (same bits)
+                    tx = (float)((1.0 + rtm::div_by_3p1415((double)rtm::atan2f_rt(normal.z, normal.x, myatan))) * 0.5);
+                    ty = (float)rtm::div_by_3p1415((double)rtm::acosf_rt(normal.y, myatan));
                 }
             }
             int ci = f2i(ty * (float)fc.tex_h) * fc.tex_w + f2i(tx * (float)fc.tex_w);
@@ -1151,7 +1172,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                 }
 #pragma unroll 1
                 for (int j = 0; j < (all_clear ? 0 : RT_SHADOW_SAMPLES); ++j) {
-                    const V3 new_dir = (fc.ablate & 2) ? chain.toL : chain.direction(fc, L, start, j);
+                    const V3 new_dir = (fc.ablate & 2) ? chain.toL : chain.direction(fc, L, start, j, myatan);
                     const RayK sr = make_ray(start, new_dir);
                     phase(6);
                     // any-hit over the list, kernel.cu:1501-1510
@@ -1297,14 +1318,19 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
 // ---------------------------------------------------------------------------
 __global__ void rt_dbg_math(int op, const float *a, const float *b, float *out, int n)
 {
+    __shared__ double atab[16];   // as the frame kernel: atan(k/8) read from LDS
+    if (threadIdx.x < 16) atab[threadIdx.x] = kAtanEighth[threadIdx.x];
+    __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float r;
     switch (op) {
     case 0: r = rtm::cosf_rt(a[i]); break;
     case 1: r = rtm::sinf_rt(a[i]); break;
-    case 2: r = rtm::acosf_rt(a[i]); break;
-    default: r = rtm::atan2f_rt(a[i], b[i]); break;
+    case 2: r = rtm::acosf_rt(a[i], atab); break;
+    case 4: r = (float)((1.0 + rtm::div_by_3p1415((double)a[i])) * 0.5); break;   // kernel.cu:1402
+    case 5: r = (float)rtm::div_by_3p1415((double)a[i]); break;                  // kernel.cu:1403
+    default: r = rtm::atan2f_rt(a[i], b[i], atab); break;
     }
     out[i] = r;
 }
@@ -1403,6 +1429,7 @@ extern "C" hipError_t rt_dev_launch_trace(const RtFrameConsts *fc, const float4 
                              (size_t)wpw * RT_LIST_CAP * sizeof(int) +   // list positions (primary order)
                              (size_t)wpw * 16 * sizeof(float) +          // brightness table per wave
                              (size_t)wpw * 64 * sizeof(int) +            // marked blocks of a culling pass
+                             (size_t)wpw * 16 * sizeof(double) +         // atan(k/8) per wave
                              (fc->n_boxes > 0 ? (size_t)wpw * RT_BOX_CAP * sizeof(int) : 0);
     const int band_h = fc->local_rows;
     const int th = 64 / tile_w;

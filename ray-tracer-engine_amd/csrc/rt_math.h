@@ -137,8 +137,10 @@ RT_HD double atan_eighth(int k)
     }
 }
 
-// atan(num/den), num >= 0, den >= 0, not both zero; result in [0, pi/2].
-RT_HD double atan_first_quadrant(double num, double den)
+// atan(num/den), num >= 0, den >= 0, not both zero; result in [0, pi/2]. `tab`, when
+// given, holds atan_eighth(0..8) (the device keeps a copy in LDS: one read instead of a
+// nine-way select of 64-bit constants).
+RT_HD double atan_first_quadrant(double num, double den, const double *tab = nullptr)
 {
     const bool swap = num > den;
     const double a = swap ? den / num : num / den;
@@ -153,11 +155,11 @@ RT_HD double atan_first_quadrant(double num, double den)
     p = p * w + -0x1.2492492492492p-3;
     p = p * w + 0x1.999999999999ap-3;
     p = p * w + -0x1.5555555555555p-2;
-    const double t = atan_eighth(idx) + (z + z * (w * p));
+    const double t = (tab ? tab[idx] : atan_eighth(idx)) + (z + z * (w * p));
     return swap ? kPio2 - t : t;
 }
 
-RT_HD double atan2_d(double y, double x)
+RT_HD double atan2_d(double y, double x, const double *tab = nullptr)
 {
     const double ay = __builtin_fabs(y), ax = __builtin_fabs(x);
     double r;
@@ -166,23 +168,35 @@ RT_HD double atan2_d(double y, double x)
     else if (__builtin_isinf(ax) && __builtin_isinf(ay))
         r = kPio4;
     else
-        r = atan_first_quadrant(ay, ax);
+        r = atan_first_quadrant(ay, ax, tab);
     if (__builtin_signbit(x)) r = kPi - r;
     return __builtin_signbit(y) ? -r : r;
 }
 
-RT_HD float atan2f_rt(float y, float x)
+RT_HD float atan2f_rt(float y, float x, const double *tab = nullptr)
 {
     if (x != x || y != y) return x + y;
-    return (float)atan2_d((double)y, (double)x);
+    return (float)atan2_d((double)y, (double)x, tab);
 }
 
-RT_HD float acosf_rt(float x)
+RT_HD float acosf_rt(float x, const double *tab = nullptr)
 {
     if (!(__builtin_fabsf(x) <= 1.0f)) return (x - x) / (x - x);
     const double xd = (double)x;
     const double s = __builtin_sqrt((1.0 - xd) * (1.0 + xd));
-    return (float)atan2_d(s, xd);
+    return (float)atan2_d(s, xd, tab);
+}
+
+// x / 3.1415 in binary64 for x = (double)(a float), without a division: q = x*RC, one
+// residual correction. Verified EXHAUSTIVELY (all 2^32 floats, tests/test_const_div.py) to
+// equal the IEEE quotient bit for bit, except that -0 gives +0 -- callers add 1.0 to the
+// result or never pass -0. The oracle keeps the plain division (kernel.cu:1402-1403).
+RT_HD double div_by_3p1415(double x)
+{
+    const double c = 3.1415, rc = 0x1.45f57ce20d722p-2;   // RN(1/3.1415)
+    const double q = x * rc;
+    const double r = __builtin_fma(-c, q, x);
+    return __builtin_fma(r, rc, q);
 }
 
 }  // namespace rtm

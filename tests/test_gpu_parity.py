@@ -54,6 +54,16 @@ def test_device_math_is_bit_identical_to_oracle(rt, oracle, gpu):
     assert lib.rt_debug_math(3, ys.ctypes.data_as(fp), xs.ctypes.data_as(fp), out.ctypes.data_as(fp), len(xs)) == 0
     want = np.array([ol.oracle_atan2f(float(y), float(x)) for y, x in zip(ys, xs)], dtype=np.float32)
     assert np.array_equal(_bits(out), _bits(want))
+    # "/ 3.1415" of kernel.cu:1402-1403 is a multiply + residual correction on the device
+    # (rtm::div_by_3p1415); the binary64 quotient is the reference (tests/test_const_div.py
+    # checks the sequence over all 2^32 floats on the CPU)
+    xs = np.concatenate([rng.uniform(-3.2, 3.2, 200000), rng.uniform(-1e-30, 1e-30, 1000),
+                         [0.0, 3.1415, -3.1415, 3.1415927, 1e-45, -1e-45, 1.5707964]]).astype(np.float32)
+    out = np.empty_like(xs)
+    assert lib.rt_debug_math(4, xs.ctypes.data_as(fp), None, out.ctypes.data_as(fp), len(xs)) == 0
+    assert np.array_equal(_bits(out), _bits(((1.0 + xs.astype(np.float64) / 3.1415) * 0.5).astype(np.float32)))
+    assert lib.rt_debug_math(5, xs.ctypes.data_as(fp), None, out.ctypes.data_as(fp), len(xs)) == 0
+    assert np.array_equal(_bits(out), _bits((xs.astype(np.float64) / 3.1415).astype(np.float32)))
 
 
 def test_device_intersect_matches_oracle(rt, oracle, gpu):

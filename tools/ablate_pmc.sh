@@ -3,14 +3,14 @@
 export TMPDIR=/tmp
 for a in 0 16 7 3 1 2 4; do
   rm -rf /tmp/ab_$a
-  RT_ABLATE=$a rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d /tmp/ab_$a -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  RT_ABLATE=$a rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d /tmp/ab_$a -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --frames-in-flight 1 > /dev/null 2>&1
   python3 - $a <<'PY'
 import csv,glob,sys,collections
 a=sys.argv[1]
 f=glob.glob(f'/tmp/ab_{a}/*/*counter_collection.csv')[0]
 agg=collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    if 'rt_trace_tiles<8, true, 0, true' in r['Kernel_Name']:
+    if 'rt_trace_tiles<8, true, 0,' in r['Kernel_Name']:
         agg[r['Counter_Name']].append(float(r['Counter_Value']))
 m={k:sum(v)/len(v) for k,v in agg.items()}
 w=129600
