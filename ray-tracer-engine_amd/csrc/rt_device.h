@@ -130,6 +130,17 @@ struct RtFrameConsts {
     const float *lsorted[RT_DEV_MAX_LIGHTS];
     const float *lblocks[RT_DEV_MAX_LIGHTS];
 
+    // for the primary rays, the table ordered by the DIRECTION of the centres as seen from the
+    // ray origin and cut into blocks of RT_BLOCK, i.e. cones from the eye. Two float4 per
+    // block: {unit axis, cos(theta)} and {sin(theta), flag, -, -}: theta bounds, for every
+    // member, the angle between the axis and any ray from the origin that can pass the
+    // member test of a beam with slope <= cone_kcap (flag 1: unbounded, always examined;
+    // -1: padding). corig: list position of every entry. Null: use `sorted`/`blocks`.
+    const float *csorted;
+    const float *cblocks;
+    const int *corig;
+    float cone_kcap, pad_cone_;
+
     // outputs
     float *rgba;                // float4 per pixel, band-local, may be null
     uint32_t *packed;           // 0x00RRGGBB per pixel, band-local, may be null

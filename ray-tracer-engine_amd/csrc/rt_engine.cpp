@@ -141,6 +141,13 @@ struct rt_scene {
     int ltab_n_lights = 0;
     float ltab_axis[RT_MAX_LIGHTS][3];   // axis each table was built for
     bool ltab_valid[RT_MAX_LIGHTS] = {};
+    // eye cones for the primary rays (see RtFrameConsts::csorted): rebuilt when the sphere
+    // list or the ray origin changes
+    float4 *d_cone_tab = nullptr;
+    size_t cap_cone_tab = 0;             // float4 units
+    unsigned long long cone_gen = ~0ull;
+    float cone_org[3] = {0, 0, 0};
+    bool cone_valid = false;
 };
 
 // Where the kernel reads the sphere table from. Default: global memory (L2-resident), LDS
@@ -182,6 +189,7 @@ extern "C" void rt_scene_destroy(rt_scene *s)
     if (s->d_tri_idx) (void)hipFree(s->d_tri_idx);
     if (s->d_box_spheres) (void)hipFree(s->d_box_spheres);
     if (s->d_light_tabs) (void)hipFree(s->d_light_tabs);
+    if (s->d_cone_tab) (void)hipFree(s->d_cone_tab);
     delete s;
 }
 
@@ -355,6 +363,137 @@ static void build_light_columns(const float4 *tab, int n, const float u_f[3], fl
         blocks[2 * b] = make_float4(cf[0], cf[1], cf[2], (float)(rho * 1.001 + 1e-3));
         blocks[2 * b + 1] = make_float4((float)(s_hi + std::fabs(s_hi) * 1e-3 + 1e-3), (float)(r3d * 1.001 + 1e-3), 0.f, 0.f);
     }
+}
+
+// ---------------------------------------------------------------------------
+// Eye cones. Every primary ray starts at the same point O, so the table is ordered by the
+// direction of the centres as seen from O (octahedral map, 2-D Morton) and cut into blocks of
+// RT_BLOCK: cones from O that a tile's thin beam meets far less often than the cubes of the
+// 3-D order. For a beam with apex O, r0 = 1e-4, smin = 0 and slope k <= kcap the member test
+// of the kernel (beam_member_test) passes only if the angle alpha between the beam axis and
+// the direction to the centre satisfies sin(alpha - atan(1.00025 k)) <= (rc (1 + k) + r0) 1.00025 / |v|,
+// rc = sqrt(R^2 + 4e-5 |v|^2 + 1e-3) 1.0001 -- all known here because the apex is. theta of
+// a block: max over members of (angle(axis, dir_j) + asin of that bound), plus margin.
+// ---------------------------------------------------------------------------
+static const float kConeKcap = 0.1f;
+
+static void oct_map(const double d[3], double *u, double *v)
+{
+    const double s = std::fabs(d[0]) + std::fabs(d[1]) + std::fabs(d[2]);
+    double x = d[0] / s, y = d[1] / s;
+    if (d[2] < 0) {
+        const double ox = (1 - std::fabs(y)) * (x >= 0 ? 1 : -1), oy = (1 - std::fabs(x)) * (y >= 0 ? 1 : -1);
+        x = ox; y = oy;
+    }
+    *u = x; *v = y;
+}
+
+static void build_eye_cones(const float4 *tab, int n, const float org[3], float4 *sorted, float4 *blocks, int *orig)
+{
+    const int n_pad = (n + 63) & ~63;
+    const double kcap = kConeKcap, r0 = 1.0e-4;
+    struct Ent { double dir[3]; double ext; bool bounded; };
+    std::vector<Ent> ent((size_t)n);
+    std::vector<std::pair<unsigned long long, int>> keys((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        Ent &e = ent[i];
+        const double v[3] = {(double)tab[i].x - org[0], (double)tab[i].y - org[1], (double)tab[i].z - org[2]};
+        const double vv = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], dist = std::sqrt(vv), w = tab[i].w;
+        e.bounded = std::isfinite(vv) && std::isfinite(w) && dist > 0;
+        e.ext = 0;
+        if (e.bounded) {
+            const double rc = std::sqrt(std::max(0.0, w) + 4.0e-5 * vv + 1.0e-3) * 1.0001;
+            const double q = (rc * (1.0 + kcap) + r0) * 1.00025 * 1.001 / dist;
+            if (!(q < 0.99)) e.bounded = false;   // the origin is inside or next to the (padded) sphere
+            else e.ext = std::asin(q);
+            for (int k = 0; k < 3; ++k) e.dir[k] = v[k] / dist;
+        }
+        unsigned long long key = ~0ull;   // unbounded entries go last
+        if (e.bounded) {
+            double ou, ov;
+            oct_map(e.dir, &ou, &ov);
+            const unsigned q1 = (unsigned)std::min(65535.0, std::max(0.0, (ou * 0.5 + 0.5) * 65535.0));
+            const unsigned q2 = (unsigned)std::min(65535.0, std::max(0.0, (ov * 0.5 + 0.5) * 65535.0));
+            key = morton16(q1) | ((unsigned long long)morton16(q2) << 1);
+        }
+        keys[i] = {key, i};
+    }
+    std::sort(keys.begin(), keys.end());
+    for (int i = 0; i < n_pad; ++i) {
+        sorted[i] = i < n ? tab[keys[i].second] : make_float4(0.f, 0.f, 0.f, 0.f);
+        orig[i] = i < n ? keys[i].second : 0x7fffffff;
+    }
+    for (int b = 0; b < n_pad / RT_BLOCK; ++b) {
+        const int i0 = b * RT_BLOCK, i1 = std::min(n, i0 + RT_BLOCK);
+        if (i0 >= n) {   // padding block: nothing in it, never examined
+            blocks[2 * b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            blocks[2 * b + 1] = make_float4(0.f, -1.f, 0.f, 0.f);
+            continue;
+        }
+        bool bounded = true;
+        double m[3] = {0, 0, 0};
+        for (int i = i0; i < i1; ++i) {
+            const Ent &e = ent[keys[i].second];
+            bounded = bounded && e.bounded;
+            if (e.bounded) for (int k = 0; k < 3; ++k) m[k] += e.dir[k];
+        }
+        const double ml = std::sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+        bounded = bounded && ml > 1e-6;
+        float af[3] = {0, 0, 0};
+        double theta = 0;
+        if (bounded) {
+            for (int k = 0; k < 3; ++k) af[k] = (float)(m[k] / ml);
+            // angles are taken from the ROUNDED axis the device will use
+            const double al = std::sqrt((double)af[0] * af[0] + (double)af[1] * af[1] + (double)af[2] * af[2]);
+            for (int i = i0; i < i1; ++i) {
+                const Ent &e = ent[keys[i].second];
+                double c = (af[0] * e.dir[0] + af[1] * e.dir[1] + af[2] * e.dir[2]) / al;
+                c = std::min(1.0, std::max(-1.0, c));
+                theta = std::max(theta, std::acos(c) + e.ext);
+            }
+            theta += 2.0e-3;
+            if (!(theta < 2.9)) bounded = false;   // theta + the beam's own angle must stay below pi
+        }
+        if (!bounded) {
+            blocks[2 * b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            blocks[2 * b + 1] = make_float4(0.f, 1.f, 0.f, 0.f);
+            continue;
+        }
+        blocks[2 * b] = make_float4(af[0], af[1], af[2], (float)std::cos(theta));
+        blocks[2 * b + 1] = make_float4((float)std::sin(theta), 0.f, 0.f, 0.f);
+    }
+}
+
+// Bring the eye cones up to date with the mirrored sphere list and the ray origin `org`
+// (= RtFrameConsts::org_*). Not inside a stream capture.
+int rt_scene_prepare_eye(rt_scene *s, const float org[3], hipStream_t stream)
+{
+    const int n = s->n_spheres;
+    const int n_pad = (n + 63) & ~63, nb = n_pad / RT_BLOCK;
+    const bool want = n >= 64 && s->h_prev.size() == (size_t)n && !getenv("RT_NO_EYE_CONES") &&
+                      std::isfinite(org[0]) && std::isfinite(org[1]) && std::isfinite(org[2]);
+    if (!want) {
+        s->cone_valid = false;
+        s->cone_gen = ~0ull;
+        return RT_OK;
+    }
+    if (s->cone_valid && s->cone_gen == s->sphere_gen && memcmp(org, s->cone_org, sizeof s->cone_org) == 0) return RT_OK;
+    const size_t total = (size_t)n_pad + 2 * (size_t)nb + ((size_t)n_pad + 3) / 4;   // float4 units
+    if (total > s->cap_cone_tab) {
+        if (s->d_cone_tab) RT_HIP(hipFree(s->d_cone_tab));
+        s->d_cone_tab = nullptr;
+        s->cap_cone_tab = 0;
+        RT_HIP(hipMalloc((void **)&s->d_cone_tab, sizeof(float4) * total));
+        s->cap_cone_tab = total;
+    }
+    std::vector<float4> h(total);
+    build_eye_cones(s->h_prev.data(), n, org, h.data(), h.data() + n_pad, reinterpret_cast<int *>(h.data() + n_pad + 2 * nb));
+    RT_HIP(hipMemcpyAsync(s->d_cone_tab, h.data(), sizeof(float4) * total, hipMemcpyHostToDevice, stream));
+    RT_HIP(hipStreamSynchronize(stream));   // `h` goes out of scope; only when the eye or the scene moved
+    s->cone_gen = s->sphere_gen;
+    memcpy(s->cone_org, org, sizeof s->cone_org);
+    s->cone_valid = true;
+    return RT_OK;
 }
 
 // Bring the per-light tables up to date with the mirrored sphere list and the lights'
@@ -670,6 +809,15 @@ extern "C" float rt_default_aspect(void)
 // frame uniforms: everything the reference recomputes per pixel from
 // frame-constant inputs, evaluated once with the same operations.
 // ---------------------------------------------------------------------------
+// eyePos + cam.Org, kernel.cu:1629-1631: the origin of every primary ray of the frame
+void rt_ray_origin(const rt_frame_desc *fd, float org[3])
+{
+    const float ez = -1.f / fd->aspect;
+    org[0] = 0.f + fd->cam.Org.x;
+    org[1] = 0.f + fd->cam.Org.y;
+    org[2] = ez + fd->cam.Org.z;
+}
+
 int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameConsts *fc)
 {
     if (!s || !fd) {
@@ -758,9 +906,13 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
     // kernel.cu:1629-1631: eyePos = (0,0,-1/aspect); dir - eyePos; eyePos + cam.Org
     const float ez = -1.f / aspect;
     fc->eye_nz = 0.f - ez;
-    fc->org_x = 0.f + fd->cam.Org.x;
-    fc->org_y = 0.f + fd->cam.Org.y;
-    fc->org_z = ez + fd->cam.Org.z;
+    {
+        float org[3];
+        rt_ray_origin(fd, org);
+        fc->org_x = org[0];
+        fc->org_y = org[1];
+        fc->org_z = org[2];
+    }
     // camera::rotateDir, kernel.cu:249-250
     const float yawRad = (float)(fd->cam.Camyaw * (3.1415 / 180));
     const float pitchRad = (float)(fd->cam.Campitch * (3.1415 / 180));
@@ -829,6 +981,13 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
             fc->lsorted[i] = on ? reinterpret_cast<const float *>(s->d_light_tabs + per_light * i) : nullptr;
             fc->lblocks[i] = on ? reinterpret_cast<const float *>(s->d_light_tabs + per_light * i + n_pad) : nullptr;
         }
+        const float org[3] = {fc->org_x, fc->org_y, fc->org_z};
+        const bool cones = s->d_cone_tab && s->cone_valid && s->cone_gen == s->sphere_gen &&
+                           memcmp(org, s->cone_org, sizeof org) == 0;
+        fc->csorted = cones ? reinterpret_cast<const float *>(s->d_cone_tab) : nullptr;
+        fc->cblocks = cones ? reinterpret_cast<const float *>(s->d_cone_tab + n_pad) : nullptr;
+        fc->corig = cones ? reinterpret_cast<const int *>(s->d_cone_tab + n_pad + 2 * (size_t)s->n_blocks) : nullptr;
+        fc->cone_kcap = kConeKcap;
     }
     fc->tris = s->d_tris;
     fc->boxes = s->d_boxes;
@@ -862,6 +1021,10 @@ extern "C" int rt_scene_render(rt_scene *s, const rt_frame_desc *fd, void *strea
         if (stream) (void)hipStreamIsCapturing((hipStream_t)stream, &cs);
         if (cs == hipStreamCaptureStatusNone) {   // a capture re-uses what rt_graph_capture prepared
             rc = rt_scene_prepare_lights(s, (hipStream_t)stream);
+            if (rc != RT_OK) return rc;
+            float org[3];
+            rt_ray_origin(fd, org);
+            rc = rt_scene_prepare_eye(s, org, (hipStream_t)stream);
             if (rc != RT_OK) return rc;
         }
     }

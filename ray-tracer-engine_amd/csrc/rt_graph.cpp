@@ -47,7 +47,11 @@ static int record_frame(rt_frame_graph *g, hipStream_t stream)
 static int capture(rt_frame_graph *g, hipStream_t stream, hipGraph_t *out)
 {
     {   // per-light tables are (re)built outside the capture; the captured launches only read them
-        const int prc = rt_scene_prepare_lights(g->scene, stream);
+        int prc = rt_scene_prepare_lights(g->scene, stream);
+        if (prc != RT_OK) return prc;
+        float org[3];
+        rt_ray_origin(&g->fd, org);
+        prc = rt_scene_prepare_eye(g->scene, org, stream);
         if (prc != RT_OK) return prc;
         RT_HIP(hipStreamSynchronize(stream));
     }

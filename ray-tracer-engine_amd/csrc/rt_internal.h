@@ -19,3 +19,5 @@ struct rt_scene;
 int rt_scene_set_spheres_async(rt_scene *s, const rt_sphere *host_spheres, int n, hipStream_t stream);
 int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameConsts *fc);
 int rt_scene_prepare_lights(rt_scene *s, hipStream_t stream);
+int rt_scene_prepare_eye(rt_scene *s, const float org[3], hipStream_t stream);
+void rt_ray_origin(const rt_frame_desc *fd, float org[3]);

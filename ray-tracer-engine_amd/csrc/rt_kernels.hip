@@ -446,16 +446,26 @@ __device__ __forceinline__ bool beam_member_test(const Beam &b, float4 s, bool e
 // that the first index still wins ties (kernel.cu:1335). Returns the survivor count
 // (with OCCL, bit 30 flags "one sphere occludes the whole beam"); a count above
 // RT_LIST_CAP tells the caller to walk the whole table instead.
-// With COLUMNS the blocks are a light's columns (csorted/cblocks, read from global memory)
-// instead of the cubes of the 3-D order.
-template <int STATS, bool TABLDS, bool OCCL, bool ORDERED, bool COLUMNS = false>
+// BLOCKS selects the first level: 0 = cubes of the 3-D order (fc.sorted/fc.blocks), 1 = a
+// light's columns, 2 = eye cones (the last two: csorted/cblocks/corig, read from global memory).
+template <int STATS, bool TABLDS, bool OCCL, bool ORDERED, int BLOCKS = 0>
 __device__ __forceinline__ int build_list2(const float4 *tab, const RtFrameConsts &fc, int n, float4 *list, int *keys,
                                            int *blist, const Beam &b, int lane, unsigned long long &n_cull,
                                            const float4 *__restrict__ csorted = nullptr,
-                                           const float4 *__restrict__ cblocks = nullptr)
+                                           const float4 *__restrict__ cblocks = nullptr,
+                                           const int *__restrict__ corig = nullptr)
 {
+    constexpr bool COLUMNS = BLOCKS != 0;   // two float4 per block, table in global memory
     const float4 *__restrict__ gsorted = COLUMNS ? csorted : reinterpret_cast<const float4 *>(fc.sorted);
     const float4 *__restrict__ gblocks = COLUMNS ? cblocks : reinterpret_cast<const float4 *>(fc.blocks);
+    const int *__restrict__ gorig = COLUMNS ? corig : fc.orig_idx;
+    // eye cones: cos and sin of the beam's own half-angle (slope padded as in the host's bound)
+    float cone_cw = 1.f, cone_sw = 0.f;
+    if (BLOCKS == 2) {
+        const float kw = b.k * 1.001f;
+        cone_cw = __builtin_amdgcn_rsqf(__builtin_fmaf(kw, kw, 1.f));
+        cone_sw = kw * cone_cw;
+    }
     const int nb = fc.n_blocks;
     int count = 0;
     bool blk = false;
@@ -465,7 +475,14 @@ __device__ __forceinline__ int build_list2(const float4 *tab, const RtFrameConst
         const int bi = bbase + lane;
         const int bc = bi < nb ? bi : nb - 1;
         bool kb;
-        if (COLUMNS) {
+        if (BLOCKS == 2) {
+            // angle(axis, beam axis) <= theta + theta_beam, both below pi (build_eye_cones)
+            const float4 ba = gblocks[2 * bc], bbx = gblocks[2 * bc + 1];
+            const float dotp = __builtin_fmaf(ba.x, b.ux, __builtin_fmaf(ba.y, b.uy, ba.z * b.uz));
+            const float rhs = __builtin_fmaf(ba.w, cone_cw, -bbx.x * cone_sw) - 2.0e-5f;   // cos(theta + theta_beam)
+            const bool inside = !(dotp < rhs);                                                 // NaN keeps the block
+            kb = (bi < nb) & (bbx.y >= 0.f) & ((bbx.y > 0.f) | inside);
+        } else if (BLOCKS == 1) {
             const float4 ba = gblocks[2 * bc], bbx = gblocks[2 * bc + 1];
             kb = (bi < nb) & (ba.w >= 0.f || ba.w != ba.w) & beam_keeps_column(b, ba, bbx);
         } else {
@@ -490,7 +507,7 @@ __device__ __forceinline__ int build_list2(const float4 *tab, const RtFrameConst
             const int pos = count + lane_prefix(m);
             if (keep && pos < RT_LIST_CAP) {
                 list[pos] = s;
-                if (ORDERED) keys[pos] = fc.orig_idx[i];
+                if (ORDERED) keys[pos] = gorig[i];
             }
             count += __popcll(m);
             if (STATS == 1) n_cull += 64;
@@ -783,7 +800,13 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
             b.smax = 0.f;
             b.r0 = 1.0e-4f;
             if (ok) {
-                const int c = build_list2<STATS, TABLDS, false, true>(tab, fc, n, mylist, mykeys, myblks, b, lane, st_cull);
+                // eye cones when the scene has them and the tile's beam is within their slope limit
+                const float4 *csorted = reinterpret_cast<const float4 *>(fc.csorted);
+                const int c = (csorted && b.k <= fc.cone_kcap)
+                                  ? build_list2<STATS, TABLDS, false, true, 2>(tab, fc, n, mylist, mykeys, myblks, b, lane, st_cull,
+                                                                              csorted, reinterpret_cast<const float4 *>(fc.cblocks),
+                                                                              fc.corig)
+                                  : build_list2<STATS, TABLDS, false, true>(tab, fc, n, mylist, mykeys, myblks, b, lane, st_cull);
                 if (c <= RT_LIST_CAP) {
                     p_use_list = true;
                     pcount = c;
@@ -1105,7 +1128,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                         // nothing -- the sample construction and the tests are skipped.
                         const bool may_skip = !fc.force_slow && !(fc.ablate & 64) && __all(!lit || zero_ok);
                         const float4 *lsorted = reinterpret_cast<const float4 *>(fc.lsorted[li]);
-                        const int cb = lsorted ? build_list2<STATS, TABLDS, true, false, true>(
+                        const int cb = lsorted ? build_list2<STATS, TABLDS, true, false, 1>(
                                                      tab, fc, n, mylist, mykeys, myblks, b, lane, st_cull, lsorted,
                                                      reinterpret_cast<const float4 *>(fc.lblocks[li]))
                                                : build_list2<STATS, TABLDS, true, false>(tab, fc, n, mylist, mykeys, myblks, b,
