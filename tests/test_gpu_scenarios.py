@@ -233,6 +233,19 @@ def test_nan_and_huge_spheres(rt, gpu):
     Scn(rt, sph).check(96, 64)
 
 
+def test_non_finite_and_enclosing_spheres_in_the_culling_tables(rt, gpu):
+    """Above 64 spheres the host builds the eye-cone and per-light column tables: entries with
+    NaN/inf centres or radii, a far giant and spheres around the camera (default Org (4,3,10))
+    and around a light must land in blocks that are always examined."""
+    rng = np.random.default_rng(18)
+    sph = [tuple(rng.uniform(0, 10, 3)) + (rng.uniform(0.2, 0.9),) for _ in range(150)]
+    sph += [(float("nan"), 1, 1, 0.5), (2, float("inf"), 3, 0.4), (3, 3, 3, float("nan")), (6, 2, 7, float("inf")),
+            (200, 150, -300, 9.0), (5, -40, 5, 6.2), (4, 3, 10.9, 1.3), (4.2, 3.1, 10.2, 0.5), (20, 20, 20, 1.5)]
+    Scn(rt, sph).check(96, 64)
+    # the same entries first in the list (ties and order of the primary list)
+    Scn(rt, sph[150:] + sph[:150]).check(64, 40)
+
+
 def test_texture_values_outside_unit_range(rt, gpu):
     """Brightness > 1 clamps at 255 in rgbToInt (kernel.cu:548-553); negative and
     non-finite texels must not be skipped by the facing-away shortcut."""
