@@ -520,15 +520,39 @@ __device__ __forceinline__ int build_list2(const float4 *tab, const RtFrameConst
         if (count > 64) {
             count = RT_LIST_CAP + 1;     // too long to reorder in one step: caller walks the table
         } else if (count > 1) {
+            // Front to back: the list is ordered by a LOWER BOUND of any t the entry can return
+            // to a ray from the apex (|D| = 1): dist - R outside the sphere, -(dist + R) inside
+            // (the near root is what intersect() returns), less 1e-3 + 2e-4 (dist + R) for the
+            // float evaluation. The caller stops as soon as every lane's nearest hit lies
+            // strictly below the next entry's bound; ties between equal t are resolved by the
+            // list positions in keys[] (first index wins, kernel.cu:1335), so the order of
+            // evaluation does not matter. The bounds go where the block list was (<= 64 entries).
+            float *lbs = reinterpret_cast<float *>(blist);
             float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
             int key = 0, rank = 0;
+            float lb = 0.f;
             if (lane < count) {
                 e = list[lane];
                 key = keys[lane];
+                const float vx = e.x - b.ax, vy = e.y - b.ay, vz = e.z - b.az;
+                const float vv = __builtin_fmaf(vx, vx, __builtin_fmaf(vy, vy, vz * vz));
+                const float dist = __builtin_amdgcn_sqrtf(vv), rr = __builtin_amdgcn_sqrtf(e.w);
+                const float slack = __builtin_fmaf(2.0e-4f, dist + rr, 1.0e-3f);
+                lb = (vv > e.w * 1.001f + 1.0e-6f) ? (dist - rr) - slack : -(dist + rr) - slack;
+                lb = (lb == lb) ? lb : -__builtin_inff();   // non-finite entries first: they never end the walk early
+                lbs[lane] = lb;
             }
-            for (int j = 0; j < count; ++j) rank += (keys[j] < key) ? 1 : 0;   // list positions are distinct
             wave_lds_sync();
-            if (lane < count) list[rank] = e;
+            for (int j = 0; j < count; ++j) {
+                const float lj = lbs[j];
+                rank += (lj < lb || (lj == lb && j < lane)) ? 1 : 0;
+            }
+            wave_lds_sync();
+            if (lane < count) {
+                list[rank] = e;
+                keys[rank] = key;
+                lbs[rank] = lb;
+            }
             wave_lds_sync();
         }
     }
@@ -860,9 +884,17 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
             if (CULL) return p_use_list ? mylist[e] : spheres[e];
             return entry_at<TABLDS>(false, mylist, tab, spheres, e);
         };
+        // A culled list comes front to back (build_list2): entry e carries its list position in
+        // mykeys[e] and a lower bound of its t in the block-list slot e. `holder` is the list
+        // position of the sphere that currently holds nt (-1: none, e.g. a triangle does), so
+        // that "first index wins ties" (kernel.cu:1335) holds in any order of evaluation.
+        const float *plbs = reinterpret_cast<const float *>(myblks);
+        const bool p_front_to_back = CULL && p_use_list && pcount > 1;
+        int holder = -1;
         float4 pcur = pcount > 0 ? primary_entry(0) : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int e = 0; e < pcount; ++e) {
             const float4 s = pcur;
+            const int pos = (CULL && p_use_list) ? mykeys[e] : e;
             pcur = primary_entry(e + 1 < pcount ? e + 1 : e);   // one entry in flight
             const Quad q = quadratic(pr, s);
             bool need = (q.disc >= 0.f);
@@ -872,8 +904,10 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                 if (need) {
                     float t;
                     if (intersect_tail(pr, q, t)) {
-                        if (t < nt) {   // strict: first index wins ties (kernel.cu:1335)
+                        // strict, and among equal t the lower list position: first index wins ties
+                        if (t < nt || (t == nt && holder >= 0 && pos < holder)) {
                             nt = t;
+                            holder = pos;
                             hcx = s.x; hcy = s.y; hcz = s.z;
                             if (MESH) hkind = 1;
                         }
@@ -881,6 +915,11 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                 }
             }
             if (STATS == 1) { st_primary += __popcll(__ballot(valid)); st_slots += 64; }
+            // every remaining entry returns t >= its bound >= the next entry's bound
+            if (p_front_to_back && e + 1 < pcount && !fc.force_slow) {
+                const float lb_next = plbs[e + 1];
+                if (__all(!valid || nt < lb_next)) break;
+            }
         }
         if (CULL) wave_lds_sync();   // the list is rebuilt below
         // cubes (kernel.cu:1344-1356) then planes (:1359-1372): few, tested exhaustively;
