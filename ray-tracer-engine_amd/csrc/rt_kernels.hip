@@ -1232,6 +1232,33 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                     unshadowed = RT_SHADOW_SAMPLES;
                     if (STATS == 1) hist[6] += 1;
                 }
+                // The samples will be walked: put the likeliest occluders first -- the spheres that
+                // reach farthest across the beam's axis (distance from the axis minus radius) -- so
+                // that the any-hit loops end sooner. An any-hit does not depend on the order.
+                if (CULL && s_use_list && !all_clear && scount > 2 && scount <= 64 && !fc.force_slow &&
+                    !(fc.ablate & 256)) {
+                    float *kbuf = reinterpret_cast<float *>(myblks);
+                    float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float key = 0.f;
+                    int rank = 0;
+                    if (lane < scount) {
+                        e = mylist[lane];
+                        const float vx = e.x - g_ax, vy = e.y - g_ay, vz = e.z - g_az;
+                        const float vv = __builtin_fmaf(vx, vx, __builtin_fmaf(vy, vy, vz * vz));
+                        const float sa = __builtin_fmaf(vx, L.ux, __builtin_fmaf(vy, L.uy, vz * L.uz));
+                        key = __builtin_amdgcn_sqrtf(__builtin_fmaxf(__builtin_fmaf(-sa, sa, vv), 0.f)) - __builtin_amdgcn_sqrtf(e.w);
+                        key = (key == key) ? key : __builtin_inff();
+                        kbuf[lane] = key;
+                    }
+                    wave_lds_sync();
+                    for (int jj = 0; jj < scount; ++jj) {
+                        const float kj = kbuf[jj];
+                        rank += (kj < key || (kj == key && jj < lane)) ? 1 : 0;
+                    }
+                    wave_lds_sync();
+                    if (lane < scount) mylist[rank] = e;
+                    wave_lds_sync();
+                }
 #pragma unroll 1
                 for (int j = 0; j < (all_clear ? 0 : RT_SHADOW_SAMPLES); ++j) {
                     const V3 new_dir = (fc.ablate & 2) ? chain.toL : chain.direction(fc, L, start, j, myatan);
