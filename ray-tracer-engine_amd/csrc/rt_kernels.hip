@@ -585,7 +585,8 @@ __device__ __forceinline__ int build_box_list(const float4 *__restrict__ bsph, i
 // ---------------------------------------------------------------------------
 struct ShadowChain {
     V3 toL;            // keeps being re-normalised in place by the reference
-    bool stable;
+    bool stable;       // an iteration leaves toL as it found it: every later iteration repeats this one
+    bool fixed1;       // normalise() maps toL to itself: later iterations can only differ in `angle`
     float angle;
     float m00, m01, m02, m10, m11, m12, m20, m21, m22;
 
@@ -595,6 +596,7 @@ struct ShadowChain {
         toL = V3{lpos.x - start.x, lpos.y - start.y, lpos.z - start.z};
         normalise_inplace(toL);
         stable = false;
+        fixed1 = false;
         angle = 0.f;
         m00 = m01 = m02 = m10 = m11 = m12 = m20 = m21 = m22 = 0.f;
     }
@@ -610,8 +612,11 @@ struct ShadowChain {
             if (!stable) {
                 const V3 tin = toL;
                 normalise_inplace(toL);
+                const V3 mid = toL;
                 normalise_inplace(toL);
-                stable = (toL.x == tin.x) && (toL.y == tin.y) && (toL.z == tin.z);
+                // unchanged by the pair, or a fixed point of normalise(): toL has its final value
+                stable = ((toL.x == tin.x) && (toL.y == tin.y) && (toL.z == tin.z)) ||
+                         ((toL.x == mid.x) && (toL.y == mid.y) && (toL.z == mid.z));
             }
         }
     }
@@ -633,27 +638,39 @@ struct ShadowChain {
                   (lpos.z + P.z * L.size) - start.z};
             const V3 toEdge = normalise_inplace(e0);                       // kernel.cu:1450
             angle = rtm::cosf_rt(dot3(toL, toEdge) * 2.f);                 // kernel.cu:1451
-            // axis = normalise(cross((0,0,1), normalise(toL))), kernel.cu:1465
-            const V3 n1 = normalise_inplace(toL);
-            V3 ax0{0.f * n1.z - 1.f * n1.y, 1.f * n1.x - 0.f * n1.z, 0.f * n1.y - 0.f * n1.x};
-            const V3 axis = normalise_inplace(ax0);
-            // nAngle = acosf(dot(normalise(toL), (0,0,1))), kernel.cu:1466
-            const V3 n2 = normalise_inplace(toL);
-            const float nAngle = rtm::acosf_rt((n2.x * 0.f + n2.y * 0.f) + n2.z * 1.f, atab);
-            float sn, cs;
-            rtm::sincosf_rt(nAngle, sn, cs);
-            const float omc = 1.f - cs;
-            // rotate(nAngle, axis), kernel.cu:1267-1277 (non-standard on purpose)
-            m00 = cs + axis.x * axis.x;
-            m01 = axis.x * axis.y * omc - axis.z * sn;
-            m02 = axis.x * axis.z * omc - axis.y * sn;
-            m10 = axis.y * axis.x * omc + axis.z * sn;
-            m11 = cs + axis.y * axis.y * omc;
-            m12 = axis.y * axis.z * omc - axis.x * sn;
-            m20 = axis.z * axis.x * omc - axis.y * sn;
-            m21 = axis.z * axis.y * omc + axis.x * sn;
-            m22 = cs + axis.z * axis.z * omc;
-            stable = (toL.x == tin.x) && (toL.y == tin.y) && (toL.z == tin.z);
+            // The rest depends on toL only through its next two in-place normalisations. Once
+            // normalise() maps toL to itself (`fixed1`, 96 % of the lanes that are not `stable`
+            // after the first iteration) those leave it -- and the axis, nAngle and the matrix
+            // -- as they are: this iteration only had a new `angle` to compute, the next ones
+            // repeat it.
+            if (!fixed1 || fc.force_slow) {
+                // axis = normalise(cross((0,0,1), normalise(toL))), kernel.cu:1465
+                const V3 n1 = normalise_inplace(toL);
+                const V3 mid = toL;
+                V3 ax0{0.f * n1.z - 1.f * n1.y, 1.f * n1.x - 0.f * n1.z, 0.f * n1.y - 0.f * n1.x};
+                const V3 axis = normalise_inplace(ax0);
+                // nAngle = acosf(dot(normalise(toL), (0,0,1))), kernel.cu:1466
+                const V3 n2 = normalise_inplace(toL);
+                const float nAngle = rtm::acosf_rt((n2.x * 0.f + n2.y * 0.f) + n2.z * 1.f, atab);
+                float sn, cs;
+                rtm::sincosf_rt(nAngle, sn, cs);
+                const float omc = 1.f - cs;
+                // rotate(nAngle, axis), kernel.cu:1267-1277 (non-standard on purpose)
+                m00 = cs + axis.x * axis.x;
+                m01 = axis.x * axis.y * omc - axis.z * sn;
+                m02 = axis.x * axis.z * omc - axis.y * sn;
+                m10 = axis.y * axis.x * omc + axis.z * sn;
+                m11 = cs + axis.y * axis.y * omc;
+                m12 = axis.y * axis.z * omc - axis.x * sn;
+                m20 = axis.z * axis.x * omc - axis.y * sn;
+                m21 = axis.z * axis.y * omc + axis.x * sn;
+                m22 = cs + axis.z * axis.z * omc;
+                fixed1 = (toL.x == mid.x) && (toL.y == mid.y) && (toL.z == mid.z) &&
+                         (n1.x == n2.x) && (n1.y == n2.y) && (n1.z == n2.z);
+                stable = (toL.x == tin.x) && (toL.y == tin.y) && (toL.z == tin.z);
+            } else {
+                stable = true;
+            }
         }
         const float z = fc.jf[j] * (1.0f - angle) + angle;                 // kernel.cu:1453
         const float sq = __builtin_sqrtf(1.f - z * z);                     // kernel.cu:1462-1463
