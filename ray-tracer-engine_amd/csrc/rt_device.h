@@ -100,6 +100,9 @@ struct RtFrameConsts {
     const float *sky_r, *sky_g, *sky_b;
     int sky_w, sky_h;
     float sky_cx, sky_cy, sky_cz, sky_r2;   // skybox sphere centre, radius*radius
+    // the ray-independent part of its quadratic (kernel.cu:293-310 with Org = the frame's ray origin),
+    // formed on the host with the same binary32 operations: oc = Org - centre, C = |oc|^2 - radius^2
+    float sky_ocx, sky_ocy, sky_ocz, sky_C;
 
     // cubes and planes: few, tested exhaustively
     const RtPlaneDev *planes;

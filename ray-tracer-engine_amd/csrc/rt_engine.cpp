@@ -963,6 +963,11 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
     fc->sky_w = s->sky_w; fc->sky_h = s->sky_h;
     fc->sky_cx = s->sky_c[0]; fc->sky_cy = s->sky_c[1]; fc->sky_cz = s->sky_c[2];
     fc->sky_r2 = s->sky_radius * s->sky_radius;
+    {   // as quadratic() evaluates them on the device (no contraction: this file is built with -ffp-contract=off)
+        const float ocx = fc->org_x - fc->sky_cx, ocy = fc->org_y - fc->sky_cy, ocz = fc->org_z - fc->sky_cz;
+        fc->sky_ocx = ocx; fc->sky_ocy = ocy; fc->sky_ocz = ocz;
+        fc->sky_C = ((ocx * ocx + ocy * ocy) + ocz * ocz) - fc->sky_r2;
+    }
     fc->planes = s->d_planes;
     fc->cubes = s->d_cubes;
     fc->n_planes = s->n_planes;

@@ -970,7 +970,13 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
         int sky_idx = -1;
         if (valid && !hit) {
             const float4 sk = make_float4(fc.sky_cx, fc.sky_cy, fc.sky_cz, fc.sky_r2);
-            const Quad q = quadratic(pr, sk);
+            // quadratic(pr, sk) with its ray-independent part (oc, C) taken from the frame constants:
+            // left to the compiler it is hoisted out of the sample loop into VGPRs and spilled
+            Quad q;
+            q.h = (pr.dx * fc.sky_ocx + pr.dy * fc.sky_ocy) + pr.dz * fc.sky_ocz;
+            q.B = 2.f * q.h;
+            q.BB = q.B * q.B;
+            q.disc = q.BB - pr.a4 * fc.sky_C;
             float t;
             intersect_tail(pr, q, t);   // the boolean is ignored there, t is used as left
             const V3 hp{O.x + D.x * t, O.y + D.y * t, O.z + D.z * t};

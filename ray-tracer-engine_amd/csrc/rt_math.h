@@ -163,12 +163,15 @@ RT_HD double atan2_d(double y, double x, const double *tab = nullptr)
 {
     const double ay = __builtin_fabs(y), ax = __builtin_fabs(x);
     double r;
-    if (ay == 0.0 && ax == 0.0)
+    if (ay == 0.0 && ax == 0.0) {
         r = 0.0;
-    else if (__builtin_isinf(ax) && __builtin_isinf(ay))
-        r = kPio4;
-    else
-        r = atan_first_quadrant(ay, ax, tab);
+    } else {
+        // inf/inf is pi/4: evaluated as atan(1/1), which is atan_eighth(8) + 0 = kPio4 exactly
+        // (a separate `r = kPio4` makes the device compiler keep that literal in registers
+        // across the whole kernel)
+        const bool both_inf = __builtin_isinf(ax) && __builtin_isinf(ay);
+        r = atan_first_quadrant(both_inf ? 1.0 : ay, both_inf ? 1.0 : ax, tab);
+    }
     if (__builtin_signbit(x)) r = kPi - r;
     return __builtin_signbit(y) ? -r : r;
 }

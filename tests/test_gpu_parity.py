@@ -48,8 +48,9 @@ def test_device_math_is_bit_identical_to_oracle(rt, oracle, gpu):
         assert lib.rt_debug_math(op, xs.ctypes.data_as(fp), None, out.ctypes.data_as(fp), len(xs)) == 0
         want = np.array([getattr(ol, names[op])(float(x)) for x in xs], dtype=np.float32)
         assert np.array_equal(_bits(out), _bits(want)), names[op]
-    ys = np.concatenate([rng.uniform(-1, 1, 60000), [0, 0, -0.0, 1, -1, 0]]).astype(np.float32)
-    xs = np.concatenate([rng.uniform(-1, 1, 60000), [1, -1, -1, 0, 0, 0]]).astype(np.float32)
+    inf = float("inf")
+    ys = np.concatenate([rng.uniform(-1, 1, 60000), [0, 0, -0.0, 1, -1, 0, inf, -inf, inf, -inf, 1, inf, -inf, 2]]).astype(np.float32)
+    xs = np.concatenate([rng.uniform(-1, 1, 60000), [1, -1, -1, 0, 0, 0, inf, inf, -inf, -inf, inf, 1, -3, -inf]]).astype(np.float32)
     out = np.empty_like(xs)
     assert lib.rt_debug_math(3, ys.ctypes.data_as(fp), xs.ctypes.data_as(fp), out.ctypes.data_as(fp), len(xs)) == 0
     want = np.array([ol.oracle_atan2f(float(y), float(x)) for y, x in zip(ys, xs)], dtype=np.float32)
