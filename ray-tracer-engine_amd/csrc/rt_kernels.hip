@@ -392,30 +392,17 @@ __device__ __forceinline__ float4 entry_at(bool use_list, const float4 *list, co
     }
 }
 
+// The member test of the culling loop: beam_keeps(), and with OCCL the question whether the
+// sphere occludes the whole beam, in one straight line -- the two share |v|^2, the axial
+// coordinate and the distance from the axis, and written with short-circuit conditions the
+// compiler wraps every clause in its own exec-mask region (a third of the loop's instructions).
+// `blocked`, only meaningful for kept entries:
 // Sphere s certainly occludes EVERY ray of the beam: it lies entirely ahead of all
 // ray origins, and the beam's cross-section at the centre's axial coordinate --
 // radius r0 + k*(sa - smin) around the axis, both already padded -- sits inside
 // the sphere shrunk by the same rounding allowance the cull test adds. Each ray
 // then passes within that shrunken radius of the centre in its forward direction,
 // so the exact float test has disc > 0 and h far below -h_sure: it returns true.
-__device__ __forceinline__ bool beam_blocked_by(const Beam &b, float4 s)
-{
-    const float vx = s.x - b.ax, vy = s.y - b.ay, vz = s.z - b.az;
-    const float vv = __builtin_fmaf(vx, vx, __builtin_fmaf(vy, vy, vz * vz));
-    const float sa = __builtin_fmaf(vx, b.ux, __builtin_fmaf(vy, b.uy, vz * b.uz));
-    const float d2 = __builtin_fmaxf(__builtin_fmaf(-sa, sa, vv), 0.f);
-    const float r2b = s.w - __builtin_fmaf(4.0e-5f, vv, 1.0e-3f);        // shrunken radius^2
-    const float rr = __builtin_amdgcn_sqrtf(s.w);
-    const bool ahead = (sa - b.smax) >= __builtin_fmaf(rr, 1.001f, 0.01f);
-    const float rho = __builtin_fmaf(b.k, sa - b.smin, b.r0);
-    const float lhs = __builtin_fmaf(__builtin_amdgcn_sqrtf(d2) + rho, 1.001f, 1.0e-4f);
-    return ahead && (r2b > 0.f) && (lhs * lhs <= r2b);
-}
-
-// beam_keeps() and beam_blocked_by() in one straight line for the culling loop: the two share
-// |v|^2, the axial coordinate and the distance from the axis, and written with short-circuit
-// conditions the compiler wraps every clause in its own exec-mask region (a third of the
-// loop's instructions). `blocked` is only meaningful for kept entries.
 template <bool OCCL>
 __device__ __forceinline__ bool beam_member_test(const Beam &b, float4 s, bool enable, bool &blocked)
 {
@@ -439,12 +426,12 @@ __device__ __forceinline__ bool beam_member_test(const Beam &b, float4 s, bool e
     return keep;
 }
 
-// Two-level cull over the Morton-ordered copy of the table: the blocks of RT_BLOCK whose
-// bounding sphere the beam can touch, then their members (64/RT_BLOCK blocks per step). Survivors come out in
-// Morton order, which is fine for an any-hit; for the primary rays (ORDERED) their
-// list positions are carried along and the short list is put back in list order so
-// that the first index still wins ties (kernel.cu:1335). Returns the survivor count
-// (with OCCL, bit 30 flags "one sphere occludes the whole beam"); a count above
+// Two-level cull over an ordered copy of the table: the blocks of RT_BLOCK the beam can touch,
+// then their members (64/RT_BLOCK blocks per step). Survivors come out in the table's order,
+// which is fine for an any-hit; for the primary rays (ORDERED) their list positions are
+// carried along in keys[] and the short list is re-ordered front to back (see below), ties
+// between equal t being settled by those positions (kernel.cu:1335). Returns the survivor
+// count (with OCCL, bit 30 flags "one sphere occludes the whole beam"); a count above
 // RT_LIST_CAP tells the caller to walk the whole table instead.
 // BLOCKS selects the first level: 0 = cubes of the 3-D order (fc.sorted/fc.blocks), 1 = a
 // light's columns, 2 = eye cones (the last two: csorted/cblocks/corig, read from global memory).
