@@ -486,6 +486,8 @@ int rt_scene_prepare_eye(rt_scene *s, const float org[3], hipStream_t stream)
         RT_HIP(hipMalloc((void **)&s->d_cone_tab, sizeof(float4) * total));
         s->cap_cone_tab = total;
     }
+    // frames still in flight (another stream, a replaying graph) may be reading the old table
+    RT_HIP(hipDeviceSynchronize());
     std::vector<float4> h(total);
     build_eye_cones(s->h_prev.data(), n, org, h.data(), h.data() + n_pad, reinterpret_cast<int *>(h.data() + n_pad + 2 * nb));
     RT_HIP(hipMemcpyAsync(s->d_cone_tab, h.data(), sizeof(float4) * total, hipMemcpyHostToDevice, stream));
@@ -532,6 +534,8 @@ int rt_scene_prepare_lights(rt_scene *s, hipStream_t stream)
         RT_HIP(hipMalloc((void **)&s->d_light_tabs, sizeof(float4) * total));
         s->cap_light_tabs = total;
     }
+    // frames still in flight (another stream, a replaying graph) may be reading the old tables
+    RT_HIP(hipDeviceSynchronize());
     std::vector<float4> h(total);
     for (int i = 0; i < s->n_lights; ++i) {
         s->ltab_valid[i] = usable[i];

@@ -143,6 +143,30 @@ def test_camera_poses(rt, gpu, yaw, pitch, org):
     Scn(rt, sph, cam=_cam(rt, org, yaw, pitch)).check(112, 80, tiles=(8,))
 
 
+def test_one_scene_many_cameras_and_moving_lights(rt, gpu):
+    """The culling tables derived from the eye (cones) and from each light (columns) are
+    cached in the scene: moving the camera or a light between frames of the SAME scene must
+    rebuild them. Every frame is compared with the brute-force loops, the last ones with the
+    oracle as well."""
+    import torch
+    rng = np.random.default_rng(21)
+    sph = [tuple(rng.uniform(0, 10, 3)) + (rng.uniform(0.1, 1.0),) for _ in range(300)]
+    base = Scn(rt, sph)
+    sc = base.scene()
+    cams = [_cam(rt), _cam(rt, (5, 5, -8), 0.0, 0.0), _cam(rt, (-6, 12, 5), 90.0, -45.0), _cam(rt),
+            _cam(rt, (4.5, 4.5, 4.5), 10.0, 5.0)]
+    for k, cam in enumerate(cams):
+        if k == 3:    # a light moves, the others stay
+            lights = (rt.Light * 3)(*rt.default_lights())
+            lights[1] = rt.Light(rt.Vec3(-15.0, 25.0, 3.0), 20.0, 0.0, 0.0, 1.0)
+            sc.set_lights(lights, 3)
+        a = sc.render(96, 64, cam=cam, cull=True)
+        b = sc.render(96, 64, cam=cam, cull=False)
+        torch.cuda.synchronize()
+        assert torch.equal(a["rgba"], b["rgba"]) and torch.equal(a["packed"], b["packed"]), k
+    Scn(rt, sph, cam=cams[-1]).check(96, 64)
+
+
 @pytest.mark.parametrize("w,h", [(1, 1), (7, 5), (67, 45), (130, 3), (9, 70)])
 def test_odd_frame_sizes(rt, gpu, w, h):
     from scenes import Inputs
