@@ -57,6 +57,8 @@ def parse():
                     help="nccl (= RCCL over xGMI) for real runs; gloo + --share-gpu only to rehearse the "
                          "N>1 code path on a box with fewer GPUs than ranks")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--gather-words", type=int, default=24, choices=[24, 32],
+                    help="N > 1: bits per pixel a rank sends to the root (24: packed word without its zero byte)")
     ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2],
                     help="consecutive frames alternate between this many HIP streams, each with its own "
                          "framebuffers (2: one frame's last waves overlap the next frame's first)")
@@ -188,15 +190,21 @@ def main():
     # frames alternate between them (and between two streams when --frames-in-flight 2), so
     # that frame i's last waves -- and, for N > 1, its gather -- overlap frame i+1's kernel.
     nfl = args.frames_in_flight
+    rgb24 = world > 1 and args.gather_words == 24 and w % 4 == 0
     rgba2 = [torch.empty((rows, w, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
     packed2 = [torch.zeros((max_rows, w), dtype=torch.int32, device="cuda") for _ in range(2)]
-    roots = [rd.InterleavedGather(h, w, world, coll_dev, BLOCK) for _ in range(2)] if (world > 1 and rank == 0) else None
+    # what a rank sends: the packed rows, or (default) their 3-bytes-per-pixel form written by the same launch
+    send2 = [torch.zeros((max_rows, rd.rgb24_row_words(w)), dtype=torch.int32, device="cuda") for _ in range(2)] \
+        if rgb24 else packed2
+    roots = [rd.InterleavedGather(h, w, world, coll_dev, BLOCK, rgb24=rgb24) for _ in range(2)] \
+        if (world > 1 and rank == 0) else None
     gathered2 = [roots[0].views, roots[1].views] if roots else [None, None]
     frame = None
     main_stream = torch.cuda.current_stream()
     streams = [torch.cuda.Stream() for _ in range(2)] if nfl == 2 else [main_stream, main_stream]
     fds = [scene.frame_desc(w, h, pixels=packed2[b].data_ptr(), rgba=rgba2[b].data_ptr(), y0=y0, y1=y1, spp=args.spp,
-                            cull=not args.no_cull, tile=args.tile, interleave=interleave) for b in range(2)]
+                            cull=not args.no_cull, tile=args.tile, interleave=interleave,
+                            packed24=send2[b].data_ptr() if rgb24 else 0) for b in range(2)]
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     pending = [None, None]
@@ -222,7 +230,7 @@ def main():
             if i is not None:
                 ev[i][1].record(streams[b])
             if world > 1:                  # the frame's single collective, asynchronous, ordered after b's kernel
-                src = packed2[b] if coll_dev == "cuda" else packed2[b].cpu()
+                src = send2[b] if coll_dev == "cuda" else send2[b].cpu()
                 if rank == 0:
                     pending[b] = dist.gather(src, gathered2[b], dst=0, async_op=True)
                 else:
@@ -269,7 +277,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         rays = w * h * args.spp
         value = rays / (ms_per_step * 1e-3) / 1e6
-        band_bytes = rows * w * (16 + 4) * 1.0      # algorithmic bytes of one launch (float4 + packed word per pixel)
+        band_bytes = rows * w * (16 + 4 + (3 if rgb24 else 0)) * 1.0   # algorithmic bytes of one launch: float4 + packed word (+ 24-bit copy for the gather) per pixel
         achieved = band_bytes / (kernel_ms * 1e-3) / 1e9
         slots = stats["wave_test_slots"] + stats["cull_tests"]     # lane slots issued for sphere/beam tests
         valu_tflops = slots * FLOP_PER_TEST / (ms_per_step * 1e-3) / 1e12
@@ -283,8 +291,9 @@ def main():
                                    f"{args.spp} spp, 3 lights x 10 shadow samples, LDS sphere-tile staging on "
                                    f"(per-tile survivor lists; RT_TABLE_LDS=1 stages the whole table instead)",
                        "cull": not args.no_cull, "tile": args.tile or 8,
-                       "parallelism": f"{BLOCK}-row blocks round-robin x{world} + 1 RCCL gather per frame "
-                                      f"(overlapped with the next frame's kernel)" if world > 1 else "single GPU",
+                       "parallelism": f"{BLOCK}-row blocks round-robin x{world} + 1 RCCL gather per frame of "
+                                      f"{24 if rgb24 else 32}-bit pixels (overlapped with the next frame's kernel)"
+                                      if world > 1 else "single GPU",
                        "frames_in_flight": nfl,
                        "outputs": "float4 RGBA + packed 0x00RRGGBB in HBM"},
             "kernel_ms": kernel_ms,

@@ -190,6 +190,10 @@ typedef struct rt_launch_opts {
                                 ((L / rows) * count + index) * rows + L % rows          */
     int interleave_index;
     int interleave_rows;     /* block height, a multiple of 16; 0 = 16                 */
+    void *packed24;          /* optional device buffer, 3 bytes per pixel (B,G,R: the packed
+                                word without its zero top byte), width*rows*3 bytes, band-local
+                                like `pixels`; needs width % 4 == 0. What a multi-GPU rank
+                                sends to the root: a quarter less than the 32-bit words      */
 } rt_launch_opts;
 
 enum { RT_STAT_PRIMARY_TESTS = 0, /* sphere tests issued for primary rays (per lane) */

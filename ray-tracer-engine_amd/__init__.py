@@ -122,7 +122,8 @@ class LaunchOpts(C.Structure):
                 ("spp", C.c_int), ("sample_base", C.c_int), ("sample_total", C.c_int),
                 ("accumulate", C.c_int), ("resolve", C.c_int), ("cull", C.c_int), ("tile", C.c_int),
                 ("stats", C.c_void_p), ("force_slow_path", C.c_int), ("profile", C.c_int),
-                ("interleave_count", C.c_int), ("interleave_index", C.c_int), ("interleave_rows", C.c_int)]
+                ("interleave_count", C.c_int), ("interleave_index", C.c_int), ("interleave_rows", C.c_int),
+                ("packed24", C.c_void_p)]
 
 
 class FrameDesc(C.Structure):
@@ -361,7 +362,7 @@ class Scene:
 
     def frame_desc(self, width, height, *, pixels=0, rgba=0, cam=None, aspect=None, y0=0, y1=0, spp=1,
                    sample_base=0, sample_total=0, accumulate=False, resolve=0, cull=True, tile=0,
-                   stats=0, force_slow=False, profile=False, interleave=None) -> FrameDesc:
+                   stats=0, force_slow=False, profile=False, interleave=None, packed24=0) -> FrameDesc:
         fd = FrameDesc()
         fd.struct_size = C.sizeof(FrameDesc)
         fd.width, fd.height = width, height
@@ -382,12 +383,13 @@ class Scene:
         o.profile = 1 if profile else 0
         if interleave is not None:          # (count, index, block_rows)
             o.interleave_count, o.interleave_index, o.interleave_rows = interleave
+        o.packed24 = packed24
         return fd
 
     def render_raw(self, fd: FrameDesc, stream=0):
         _check(self.lib.rt_scene_render(self.handle, C.byref(fd), stream), "rt_scene_render")
 
-    def render(self, width, height, *, y0=0, y1=0, want_rgba=True, want_stats=False, stream=None, **kw):
+    def render(self, width, height, *, y0=0, y1=0, want_rgba=True, want_stats=False, want_packed24=False, stream=None, **kw):
         """Render rows [y0,y1) into fresh torch CUDA tensors and return
         {'packed': int32 [rows, W], 'rgba': float32 [rows, W, 4], 'stats': dict}."""
         import torch
@@ -401,10 +403,14 @@ class Scene:
         rgba = torch.empty((rows, width, 4), dtype=torch.float32, device="cuda") if want_rgba else None
         stats = torch.zeros(RT_STATS_COUNT, dtype=torch.int64, device="cuda") if want_stats else None
         st = torch.cuda.current_stream() if stream is None else stream
+        p24 = torch.zeros((rows, width * 3 // 4), dtype=torch.int32, device="cuda") if want_packed24 else None
         fd = self.frame_desc(width, height, pixels=packed.data_ptr(), rgba=rgba.data_ptr() if want_rgba else 0,
-                             y0=y0, y1=y1, stats=stats.data_ptr() if want_stats else 0, **kw)
+                             y0=y0, y1=y1, stats=stats.data_ptr() if want_stats else 0,
+                             packed24=p24.data_ptr() if want_packed24 else 0, **kw)
         self.render_raw(fd, st.cuda_stream)
         out = {"packed": packed, "rgba": rgba}
+        if want_packed24:
+            out["packed24"] = p24     # [rows, 3*width/4] int32: bytes B,G,R per pixel (rt_launch_opts.packed24)
         if want_stats:
             out["stats"] = dict(zip(STAT_NAMES, stats.cpu().tolist()))
         return out

@@ -147,5 +147,6 @@ struct RtFrameConsts {
     // outputs
     float *rgba;                // float4 per pixel, band-local, may be null
     uint32_t *packed;           // 0x00RRGGBB per pixel, band-local, may be null
+    uint32_t *packed24;         // the same without the zero byte: 3 dwords per 4 pixels, may be null (width % 4 == 0)
     unsigned long long *stats;  // RT_STATS_COUNT counters, may be null
 };

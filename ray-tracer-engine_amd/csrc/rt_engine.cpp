@@ -877,7 +877,7 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
     fc->sample_base = o.sample_base;
     fc->sample_total = (float)total;
     fc->accumulate = o.accumulate ? 1 : 0;
-    fc->resolve = (fd->pixels && o.resolve >= 0) ? 1 : 0;
+    fc->resolve = ((fd->pixels || o.packed24) && o.resolve >= 0) ? 1 : 0;
     fc->local_rows = y1 - y0;
     if (o.interleave_count > 1) {
         const int b = o.interleave_rows > 0 ? o.interleave_rows : 16;
@@ -1006,6 +1006,11 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
     fc->mesh_has_normals = s->mesh_has_normals;
     fc->rgba = o.rgba;
     fc->packed = fd->pixels;
+    fc->packed24 = (uint32_t *)o.packed24;
+    if (o.packed24 && fd->width % 4 != 0) {
+        rt_set_error("rt_scene_render: packed24 needs a frame width that is a multiple of 4 (got %d)", fd->width);
+        return RT_ERR_INVALID;
+    }
     fc->stats = (unsigned long long *)o.stats;
     return RT_OK;
 }

@@ -1376,6 +1376,21 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
             fc.packed[o] = rgb_to_int(f2i(mr * 254.f), f2i(mg * 254.f), f2i(mb * 254.f));
         }
     }
+    if (fc.packed24 && fc.resolve) {   // wave-uniform; all lanes take part in the quad exchange
+        float mr = acc_r, mg = acc_g, mb = acc_b;
+        if (fc.sample_total != 1.f) {
+            mr = acc_r / fc.sample_total;
+            mg = acc_g / fc.sample_total;
+            mb = acc_b / fc.sample_total;
+        }
+        const unsigned p = rgb_to_int(f2i(mr * 254.f), f2i(mg * 254.f), f2i(mb * 254.f));
+        // the next pixel of the quad (lanes 4q..4q+3 hold four consecutive pixels of a row)
+        const unsigned pn = (unsigned)__builtin_amdgcn_update_dpp(0, (int)p, 0xF9 /* quad_perm [1,2,3,3] */, 0xf, 0xf, true);
+        const int i = lane & 3;
+        // bytes B,G,R of pixel k at 3k..3k+2: dword i of the quad's three
+        const unsigned w24 = (p >> (8 * i)) | (pn << (24 - 8 * i));
+        if (valid && i < 3) fc.packed24[(size_t)(out_idx >> 2) * 3 + (size_t)i] = w24;
+    }
 
     phase(3, true);
     if (STATS == 2 && fc.stats) {

@@ -70,23 +70,48 @@ def assemble_interleaved(gathered, height: int, block: int = 16, out=None) -> to
     return out
 
 
+def rgb24_row_words(width: int) -> int:
+    """int32 words of one row in the 3-bytes-per-pixel form (`rt_launch_opts.packed24`)."""
+    if width % 4:
+        raise ValueError("the 24-bit row form needs a width that is a multiple of 4")
+    return width * 3 // 4
+
+
+def unpack_rgb24(rows24: torch.Tensor, width: int, out=None) -> torch.Tensor:
+    """[rows, 3*width/4] int32 (bytes B,G,R per pixel) -> [rows, width] int32 words 0x00RRGGBB,
+    the form `setPixelBuff` consumes. `out`, if given, must have its top bytes already zero."""
+    rows = rows24.shape[0]
+    if out is None:
+        out = torch.zeros((rows, width), dtype=torch.int32, device=rows24.device)
+    out.view(torch.uint8).view(rows, width, 4)[..., :3].copy_(rows24.view(torch.uint8).view(rows, width, 3))
+    return out
+
+
 class InterleavedGather:
     """Root-side buffers for the interleaved split: one contiguous receive buffer
     whose per-rank slices are the gather list, and a row permutation so that the
-    whole frame is put in place by ONE index_select kernel per frame."""
+    whole frame is put in place by ONE index_select kernel per frame. With `rgb24`
+    the ranks send 3 bytes per pixel (the packed word without its zero byte, a quarter
+    less over xGMI) and the root widens the assembled frame back to 32-bit words."""
 
-    def __init__(self, height: int, width: int, world: int, device, block: int = 16, dtype=torch.int32):
-        self.height, self.world, self.block = height, world, block
+    def __init__(self, height: int, width: int, world: int, device, block: int = 16, dtype=torch.int32,
+                 rgb24: bool = False):
+        self.height, self.width, self.world, self.block, self.rgb24 = height, width, world, block, rgb24
         self.max_rows = max_interleaved_rows(height, world, block)
-        self.recv = torch.empty((world, self.max_rows, width), dtype=dtype, device=device)
+        self.row_words = rgb24_row_words(width) if rgb24 else width
+        self.recv = torch.empty((world, self.max_rows, self.row_words), dtype=dtype, device=device)
         self.views = [self.recv[r] for r in range(world)]
         src = torch.empty(height, dtype=torch.int64)
         for r in range(world):
             rows = interleaved_rows(height, r, world, block)
             src[torch.as_tensor(rows)] = r * self.max_rows + torch.arange(len(rows))
         self.src_rows = src.to(device)            # frame row y comes from recv.view(-1, W)[src_rows[y]]
-        self.frame = torch.empty((height, width), dtype=dtype, device=device)
+        self.frame = torch.zeros((height, width), dtype=dtype, device=device)
+        self.frame24 = torch.empty((height, self.row_words), dtype=dtype, device=device) if rgb24 else None
 
     def assemble(self) -> torch.Tensor:
+        if self.rgb24:
+            torch.index_select(self.recv.view(self.world * self.max_rows, -1), 0, self.src_rows, out=self.frame24)
+            return unpack_rgb24(self.frame24, self.width, out=self.frame)
         torch.index_select(self.recv.view(self.world * self.max_rows, -1), 0, self.src_rows, out=self.frame)
         return self.frame

@@ -70,6 +70,12 @@ def _worker_interleaved(rank, world, port, w, h, out_path):
         b = root.assemble()                       # the one-kernel variant bench.py uses
         assert torch.equal(a, b)
         np.save(out_path, b.numpy())
+    # the same frame sent as 3 bytes per pixel (what bench.py gathers by default)
+    band24 = band.view(torch.uint8).view(band.shape[0], w, 4)[..., :3].contiguous().view(band.shape[0], -1).view(torch.int32)
+    root24 = rd.InterleavedGather(h, w, world, "cpu", rgb24=True) if rank == 0 else None
+    rd.gather_bands(band24, dst=0, out=root24.views if root24 else None)
+    if rank == 0:
+        assert torch.equal(root24.assemble(), b)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -97,3 +103,17 @@ def test_band_gather_reassembles_frame(world, h, tmp_path, rt, oracle):
     _, want, _ = Inputs(rt, n).oracle_render(oracle, w, h)
     assert frame.shape == (h, w)
     assert np.array_equal(frame, want)
+
+
+def test_rgb24_rows_widen_back_to_packed_words():
+    """distributed.unpack_rgb24: the 3-bytes-per-pixel rows a rank sends are the packed words
+    0x00RRGGBB without their zero byte (little endian: B, G, R)."""
+    import torch
+    from ray_tracer_engine_amd import distributed as rd
+    g = torch.Generator().manual_seed(5)
+    words = torch.randint(0, 1 << 24, (7, 24), generator=g, dtype=torch.int32)
+    rows24 = words.view(torch.uint8).view(7, 24, 4)[..., :3].contiguous().view(7, 72).view(torch.int32)
+    assert rows24.shape == (7, rd.rgb24_row_words(24))
+    assert torch.equal(rd.unpack_rgb24(rows24, 24), words)
+    with pytest.raises(ValueError):
+        rd.rgb24_row_words(22)

@@ -440,3 +440,22 @@ def test_cxx_application_shell_with_its_own_window(rt, gpu, tmp_path):
     got = (rgb[..., 0] << 16) + (rgb[..., 1] << 8) + rgb[..., 2]
     _, want, _ = Inputs(rt, 256).oracle_render(oracle_py, 160, 90)
     assert np.array_equal(got, want)
+
+
+def test_packed24_is_the_packed_frame_without_its_zero_byte(rt, gpu):
+    """rt_launch_opts.packed24 (what a multi-GPU rank sends to the root): 3 bytes per pixel,
+    B,G,R, written by the same launch; widened back it equals the 32-bit frame, for every tile
+    shape, a row band, interleaved rows and 4 spp. Widths that are not a multiple of 4 are refused."""
+    import torch
+    from scenes import Inputs
+    from ray_tracer_engine_amd import distributed as rd
+    sc = Inputs(rt, 256).scene()
+    for kw in ({}, {"tile": 16}, {"tile": 32}, {"tile": 64}, {"spp": 4}, {"y0": 24, "y1": 56},
+               {"interleave": (3, 1, 16)}, {"cull": False}):
+        out = sc.render(160, 88, want_packed24=True, **kw)
+        torch.cuda.synchronize()
+        wide = rd.unpack_rgb24(out["packed24"], 160)
+        assert torch.equal(wide, out["packed"]), kw
+        assert int((out["packed"].view(torch.uint8).view(-1, 4)[:, 3] != 0).sum()) == 0
+    with pytest.raises(rt.RtError):
+        sc.render(162, 40, want_packed24=True)
