@@ -509,8 +509,13 @@ __device__ __forceinline__ int build_list2(const float4 *tab, const RtFrameConst
         } else if (count > 1) {
             // Front to back: the list is ordered by a LOWER BOUND of any t the entry can return
             // to a ray from the apex (|D| = 1): dist - R outside the sphere, -(dist + R) inside
-            // (the near root is what intersect() returns), less 1e-3 + 2e-4 (dist + R) for the
-            // float evaluation. The caller stops as soon as every lane's nearest hit lies
+            // (the near root is what intersect() returns), less an allowance for the float
+            // evaluation. That allowance is set by grazing rays: B^2 - 4AC is formed with an
+            // absolute error of about 12 ulp(dist^2) = 3e-6 dist^2, so sqrt(disc) -- and with it
+            // the near root -- can be off by sqrt(7.5e-7) dist = 8.7e-4 dist where the exact
+            // discriminant vanishes (where it does not, the error is far smaller and the exact
+            // root exceeds dist - R by up to R): 1e-3 + 1.5e-3 (dist + R) covers both cases.
+            // The caller stops as soon as every lane's nearest hit lies
             // strictly below the next entry's bound; ties between equal t are resolved by the
             // list positions in keys[] (first index wins, kernel.cu:1335), so the order of
             // evaluation does not matter. The bounds go where the block list was (<= 64 entries).
@@ -524,7 +529,7 @@ __device__ __forceinline__ int build_list2(const float4 *tab, const RtFrameConst
                 const float vx = e.x - b.ax, vy = e.y - b.ay, vz = e.z - b.az;
                 const float vv = __builtin_fmaf(vx, vx, __builtin_fmaf(vy, vy, vz * vz));
                 const float dist = __builtin_amdgcn_sqrtf(vv), rr = __builtin_amdgcn_sqrtf(e.w);
-                const float slack = __builtin_fmaf(2.0e-4f, dist + rr, 1.0e-3f);
+                const float slack = __builtin_fmaf(1.5e-3f, dist + rr, 1.0e-3f);
                 lb = (vv > e.w * 1.001f + 1.0e-6f) ? (dist - rr) - slack : -(dist + rr) - slack;
                 lb = (lb == lb) ? lb : -__builtin_inff();   // non-finite entries first: they never end the walk early
                 lbs[lane] = lb;
