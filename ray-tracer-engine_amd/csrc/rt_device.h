@@ -113,7 +113,9 @@ struct RtFrameConsts {
     const RtTriDev *tris;
     const RtBoxDev *boxes;
     const int *tri_idx;
-    const float *box_spheres;   // float4 per leaf: bounding sphere {cx,cy,cz,r^2} for beam culling
+    const float *box_spheres;   // float4 per leaf: bounding sphere {cx,cy,cz,r^2} for beam culling (+ blocks of leaves)
+    const float *tri9;          // the three vertices (9 floats) of every (leaf, triangle) pair in the order of
+                                // tri_idx: a leaf's triangles are contiguous, one coalesced load stages 7 of them
     int n_boxes, mesh_has_normals;
 
     // the sphere table once more in Morton order of the centres, cut into blocks of 64

@@ -131,6 +131,7 @@ struct rt_scene {
     RtBoxDev *d_boxes = nullptr;
     int *d_tri_idx = nullptr;
     float *d_box_spheres = nullptr;
+    float *d_tri9 = nullptr;
     int n_boxes = 0, n_tris = 0, mesh_has_normals = 0;
     // per-light column blocks (see RtFrameConsts::lsorted): one allocation, rebuilt when the
     // sphere list or a light's position changes
@@ -188,6 +189,7 @@ extern "C" void rt_scene_destroy(rt_scene *s)
     if (s->d_boxes) (void)hipFree(s->d_boxes);
     if (s->d_tri_idx) (void)hipFree(s->d_tri_idx);
     if (s->d_box_spheres) (void)hipFree(s->d_box_spheres);
+    if (s->d_tri9) (void)hipFree(s->d_tri9);
     if (s->d_light_tabs) (void)hipFree(s->d_light_tabs);
     if (s->d_cone_tab) (void)hipFree(s->d_cone_tab);
     delete s;
@@ -669,6 +671,8 @@ extern "C" int rt_scene_set_mesh(rt_scene *s, const rt_mesh *mesh)
     if (s->d_boxes) RT_HIP(hipFree(s->d_boxes));
     if (s->d_tri_idx) RT_HIP(hipFree(s->d_tri_idx));
     if (s->d_box_spheres) RT_HIP(hipFree(s->d_box_spheres));
+    if (s->d_tri9) RT_HIP(hipFree(s->d_tri9));
+    s->d_tri9 = nullptr;
     s->d_tris = nullptr; s->d_boxes = nullptr; s->d_tri_idx = nullptr; s->d_box_spheres = nullptr;
     s->n_boxes = s->n_tris = 0;
     if (!mesh || mesh->bvhbox_count == 0) return RT_OK;
@@ -721,11 +725,46 @@ extern "C" int rt_scene_set_mesh(rt_scene *s, const rt_mesh *mesh)
     RT_HIP(hipMalloc((void **)&s->d_tris, sizeof(RtTriDev) * tris.size()));
     RT_HIP(hipMalloc((void **)&s->d_boxes, sizeof(RtBoxDev) * boxes.size()));
     RT_HIP(hipMalloc((void **)&s->d_tri_idx, sizeof(int) * (idx.size() ? idx.size() : 1)));
+    {   // blocks of RT_BLOCK consecutive leaves (leaf order is kept: it decides ties between triangles),
+        // each with a sphere around its members' spheres, appended after the (padded) leaf spheres
+        const int nb = mesh->bvhbox_count, nb_pad = (nb + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK, nblk = nb_pad / RT_BLOCK;
+        bsph.resize((size_t)(nb_pad + nblk) * 4, 0.f);
+        for (int j = nb; j < nb_pad; ++j) bsph[4 * (size_t)j + 3] = -1.f;
+        for (int k = 0; k < nblk; ++k) {
+            const int j0 = k * RT_BLOCK, j1 = std::min(nb, j0 + RT_BLOCK);
+            double cx = 0, cy = 0, cz = 0;
+            for (int j = j0; j < j1; ++j) { cx += bsph[4 * (size_t)j]; cy += bsph[4 * (size_t)j + 1]; cz += bsph[4 * (size_t)j + 2]; }
+            const double inv = 1.0 / std::max(1, j1 - j0);
+            const float cf[3] = {(float)(cx * inv), (float)(cy * inv), (float)(cz * inv)};
+            double r = 0;
+            for (int j = j0; j < j1; ++j) {
+                const double dx = bsph[4 * (size_t)j] - (double)cf[0], dy = bsph[4 * (size_t)j + 1] - (double)cf[1],
+                             dz = bsph[4 * (size_t)j + 2] - (double)cf[2];
+                const double d = std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt(std::max(0.0, (double)bsph[4 * (size_t)j + 3]));
+                r = (d > r || d != d) ? d : r;   // a NaN sticks
+            }
+            float rf = (float)(r * 1.001 + 1e-3);
+            const bool fin = std::isfinite(cf[0]) && std::isfinite(cf[1]) && std::isfinite(cf[2]) && rf == rf;
+            float *o = &bsph[4 * (size_t)(nb_pad + k)];
+            o[0] = fin ? cf[0] : 0.f; o[1] = fin ? cf[1] : 0.f; o[2] = fin ? cf[2] : 0.f;
+            o[3] = fin ? rf : INFINITY;
+        }
+    }
     RT_HIP(hipMalloc((void **)&s->d_box_spheres, sizeof(float) * bsph.size()));
     RT_HIP(hipMemcpy(s->d_box_spheres, bsph.data(), sizeof(float) * bsph.size(), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(s->d_tris, tris.data(), sizeof(RtTriDev) * tris.size(), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(s->d_boxes, boxes.data(), sizeof(RtBoxDev) * boxes.size(), hipMemcpyHostToDevice));
     if (!idx.empty()) RT_HIP(hipMemcpy(s->d_tri_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
+    {   // vertices per (leaf, triangle) pair, de-indexed and padded by 64 floats so that a full-wave load stays inside
+        std::vector<float> t9(idx.size() * 9 + 64, 0.f);
+        for (size_t k = 0; k < idx.size(); ++k) {
+            memcpy(&t9[9 * k + 0], tris[idx[k]].p0, 12);
+            memcpy(&t9[9 * k + 3], tris[idx[k]].p1, 12);
+            memcpy(&t9[9 * k + 6], tris[idx[k]].p2, 12);
+        }
+        RT_HIP(hipMalloc((void **)&s->d_tri9, sizeof(float) * t9.size()));
+        RT_HIP(hipMemcpy(s->d_tri9, t9.data(), sizeof(float) * t9.size(), hipMemcpyHostToDevice));
+    }
     s->n_boxes = mesh->bvhbox_count;
     s->n_tris = mesh->poly_count;
     s->mesh_has_normals = mesh->has_normals ? 1 : 0;
@@ -1002,6 +1041,7 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
     fc->boxes = s->d_boxes;
     fc->tri_idx = s->d_tri_idx;
     fc->box_spheres = s->d_box_spheres;
+    fc->tri9 = s->d_tri9;
     fc->n_boxes = s->n_boxes;
     fc->mesh_has_normals = s->mesh_has_normals;
     fc->rgba = o.rgba;

@@ -555,18 +555,38 @@ __device__ __forceinline__ int build_list2(const float4 *tab, const RtFrameConst
 // Leaf boxes of the mesh that the beam can touch, as indices in leaf order. A ray
 // tests a leaf's triangles only after passing the leaf's slab test, i.e. only if
 // it crosses the box, hence its bounding sphere: the sphere test with the usual
-// padding is conservative. Order is kept (first triangle wins ties, kernel.cu:1309).
-__device__ __forceinline__ int build_box_list(const float4 *__restrict__ bsph, int nb, int *list, const Beam &b, int lane)
+// padding is conservative. Order is kept (first triangle wins ties, kernel.cu:1309):
+// two levels as for the spheres, but over blocks of RT_BLOCK CONSECUTIVE leaves (the host
+// appends their bounding spheres after the leaf spheres), marked blocks and their members
+// both taken in increasing order.
+__device__ __forceinline__ int build_box_list(const float4 *__restrict__ bsph, int nb, int *list, int *blist, const Beam &b,
+                                              int lane)
 {
+    const int nb_pad = (nb + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK, nblk = nb_pad / RT_BLOCK;
+    const float4 *__restrict__ blocks = bsph + nb_pad;
+    constexpr int G = 64 / RT_BLOCK;
+    const int grp = lane / RT_BLOCK, sub = lane % RT_BLOCK;
     int count = 0;
-    for (int base = 0; base < nb; base += 64) {
-        const int i = base + lane;
-        const float4 s = bsph[i < nb ? i : nb - 1];
-        const bool keep = (i < nb) && beam_keeps(b, s);
-        const unsigned long long m = __ballot(keep);
-        const int pos = count + lane_prefix(m);
-        if (keep && pos < RT_BOX_CAP) list[pos] = i;
-        count += __popcll(m);
+    for (int bbase = 0; bbase < nblk; bbase += 64) {
+        const int bi = bbase + lane;
+        const float4 bb = blocks[bi < nblk ? bi : nblk - 1];
+        const bool kb = (bi < nblk) && beam_keeps_block(b, bb);
+        const unsigned long long bm = __ballot(kb);
+        const int marked = __popcll(bm);
+        if (kb) blist[lane_prefix(bm)] = bi;
+        wave_lds_sync();
+        for (int t = 0; t < marked; t += G) {
+            const int slot = t + grp;
+            const int blk = (slot < marked) ? blist[slot] : -1;
+            const int i = (blk < 0 ? 0 : blk) * RT_BLOCK + sub;
+            const float4 s = bsph[i];
+            const bool keep = (blk >= 0) && (i < nb) && beam_keeps(b, s);
+            const unsigned long long m = __ballot(keep);
+            const int pos = count + lane_prefix(m);
+            if (keep && pos < RT_BOX_CAP) list[pos] = i;
+            count += __popcll(m);
+        }
+        if (bbase + 64 < nblk) wave_lds_sync();
     }
     wave_lds_sync();
     return count;
@@ -746,7 +766,8 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
     double *myatan = reinterpret_cast<double *>(reinterpret_cast<int *>(lds + (TABLDS ? n_pad : 0) + WPW * RT_LIST_CAP) +
                                                 WPW * (RT_LIST_CAP + 16 + 64)) + wave * 16;
     int *myboxes = reinterpret_cast<int *>(lds + (TABLDS ? n_pad : 0) + WPW * RT_LIST_CAP) +
-                   WPW * (RT_LIST_CAP + 16 + 64 + 32) + wave * RT_BOX_CAP;
+                   WPW * (RT_LIST_CAP + 16 + 64 + 32) + wave * (RT_BOX_CAP + 128);   // + marked leaf blocks + 64 staged floats
+    float *mytri = reinterpret_cast<float *>(myboxes + RT_BOX_CAP + 64);   // staged vertices of a leaf (MESH launches only)
     if (lane < 16) {
         mybtab[lane] = kBrightnessSteps[lane];   // same values as brightness_steps()
         myatan[lane] = kAtanEighth[lane];
@@ -848,7 +869,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                 }
                 if (STATS == 1) st_entries += (unsigned long long)(c <= RT_LIST_CAP ? c : n);
                 if (MESH) {
-                    const int cb = build_box_list(reinterpret_cast<const float4 *>(fc.box_spheres), fc.n_boxes, myboxes, b, lane);
+                    const int cb = build_box_list(reinterpret_cast<const float4 *>(fc.box_spheres), fc.n_boxes, myboxes, myboxes + RT_BOX_CAP, b, lane);
                     if (cb <= RT_BOX_CAP) {
                         pb_use_list = true;
                         pbcount = cb;
@@ -872,17 +893,25 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                 const RtBoxDev bx = fc.boxes[j];
                 const bool bh = box_intersect(bx, O, inv);
                 if (__any(bh)) {
-                    for (int i = 0; i < bx.len; ++i) {
-                        const int idx = fc.tri_idx[bx.start + i];
-                        const RtTriDev *tp = fc.tris + idx;
-                        float t, u, v;
-                        if (bh && tri_intersect(O, D, tp->p0, tp->p1, tp->p2, t, u, v) && t < nt) {
-                            nt = t;
-                            hnu = u;
-                            hnv = v;
-                            htri = idx;
-                            hkind = 0;
+                    // the leaf's vertices, seven triangles (63 floats) per coalesced load, staged in LDS
+                    // and broadcast from there: one memory round trip per seven triangles instead of
+                    // two dependent scalar loads per triangle
+                    for (int base = 0; base < bx.len; base += 7) {
+                        const int cnt = bx.len - base < 7 ? bx.len - base : 7;
+                        mytri[lane] = fc.tri9[(size_t)(bx.start + base) * 9 + lane];   // the array is padded by 64 floats
+                        wave_lds_sync();
+                        for (int i = 0; i < cnt; ++i) {
+                            const float *tv = mytri + 9 * i;
+                            float t, u, v;
+                            if (bh && tri_intersect(O, D, tv, tv + 3, tv + 6, t, u, v) && t < nt) {
+                                nt = t;
+                                hnu = u;
+                                hnv = v;
+                                htri = bx.start + base + i;   // position in tri_idx; resolved when shading
+                                hkind = 0;
+                            }
                         }
+                        wave_lds_sync();
                     }
                 }
             }
@@ -990,7 +1019,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
             float tx = 0.5f, ty = 0.5f;   // plane, kernel.cu:1413-1414
             V3 hp = new_org;              // what start_O is offset from
             if (MESH && hkind == 0) {     // triangle, kernel.cu:1378-1393
-                const RtTriDev *tp = fc.tris + htri;
+                const RtTriDev *tp = fc.tris + fc.tri_idx[htri];
                 const float w0 = 1 - hnu - hnv;
                 if (fc.mesh_has_normals) {
                     normal = V3{(tp->vn[0] * w0 + tp->vn[3] * hnu) + tp->vn[6] * hnv,
@@ -1194,7 +1223,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                             continue;
                         }
                         if (MESH) {
-                            const int cbx = build_box_list(reinterpret_cast<const float4 *>(fc.box_spheres), fc.n_boxes, myboxes, b, lane);
+                            const int cbx = build_box_list(reinterpret_cast<const float4 *>(fc.box_spheres), fc.n_boxes, myboxes, myboxes + RT_BOX_CAP, b, lane);
                             if (cbx <= RT_BOX_CAP) {
                                 sb_use_list = true;
                                 sbcount = cbx;
@@ -1303,11 +1332,17 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                             const RtBoxDev bx = fc.boxes[bj];
                             const bool bh = !shadowed && box_intersect(bx, start, inv);
                             if (__any(bh)) {
-                                for (int i = 0; i < bx.len; ++i) {
-                                    const RtTriDev *tp = fc.tris + fc.tri_idx[bx.start + i];
-                                    float t, u, v;
-                                    if (bh && !shadowed && tri_intersect(start, new_dir, tp->p0, tp->p1, tp->p2, t, u, v))
-                                        shadowed = true;
+                                for (int base = 0; base < bx.len; base += 7) {
+                                    const int cnt = bx.len - base < 7 ? bx.len - base : 7;
+                                    mytri[lane] = fc.tri9[(size_t)(bx.start + base) * 9 + lane];
+                                    wave_lds_sync();
+                                    for (int i = 0; i < cnt; ++i) {
+                                        const float *tv = mytri + 9 * i;
+                                        float t, u, v;
+                                        if (bh && !shadowed && tri_intersect(start, new_dir, tv, tv + 3, tv + 6, t, u, v))
+                                            shadowed = true;
+                                    }
+                                    wave_lds_sync();
                                 }
                                 if (__all(shadowed)) break;
                             }
@@ -1549,7 +1584,7 @@ extern "C" hipError_t rt_dev_launch_trace(const RtFrameConsts *fc, const float4 
                              (size_t)wpw * 16 * sizeof(float) +          // brightness table per wave
                              (size_t)wpw * 64 * sizeof(int) +            // marked blocks of a culling pass
                              (size_t)wpw * 16 * sizeof(double) +         // atan(k/8) per wave
-                             (fc->n_boxes > 0 ? (size_t)wpw * RT_BOX_CAP * sizeof(int) : 0);
+                             (fc->n_boxes > 0 ? (size_t)wpw * (RT_BOX_CAP + 128) * sizeof(int) : 0);
     const int band_h = fc->local_rows;
     const int th = 64 / tile_w;
     const int wgx = (tile_w <= 16 && wpw >= 2) ? 2 : 1;
