@@ -888,11 +888,11 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
             // triangles through the flat list of leaf boxes, kernel.cu:1293-1328 (before
             // the spheres, as there): a lane tests a leaf's triangles iff its ray hits the box
             const V3 inv{1.f / D.x, 1.f / D.y, 1.f / D.z};
-            for (int jj = 0; jj < pbcount; ++jj) {
+            for (int jj = 0; jj < ((fc.ablate & 2048) ? 0 : pbcount); ++jj) {
                 const int j = pb_use_list ? myboxes[jj] : jj;
                 const RtBoxDev bx = fc.boxes[j];
                 const bool bh = box_intersect(bx, O, inv);
-                if (__any(bh)) {
+                if (__any(bh) && !(fc.ablate & 1024)) {
                     // the leaf's vertices, seven triangles (63 floats) per coalesced load, staged in LDS
                     // and broadcast from there: one memory round trip per seven triangles instead of
                     // two dependent scalar loads per triangle
