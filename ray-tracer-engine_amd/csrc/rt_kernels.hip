@@ -1175,23 +1175,30 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                         // (The ten samples themselves come within a few per cent of this bound; walking
                         // them cost 250 instructions per light.) A NaN or inf anywhere makes kmax2 a NaN,
                         // which switches culling off below.
-                        const float a0x = m01 * b.uz - m02 * b.uy, a0y = m02 * b.ux - m00 * b.uz, a0z = m00 * b.uy - m01 * b.ux;
-                        const float a1x = m11 * b.uz - m12 * b.uy, a1y = m12 * b.ux - m10 * b.uz, a1z = m10 * b.uy - m11 * b.ux;
-                        const float a2x = m21 * b.uz - m22 * b.uy, a2y = m22 * b.ux - m20 * b.uz, a2z = m20 * b.uy - m21 * b.ux;
-                        const float frob2 = m00 * m00 + m01 * m01 + m02 * m02 + m10 * m10 + m11 * m11 + m12 * m12 +
-                                            m20 * m20 + m21 * m21 + m22 * m22;
+                        // |Ri x u|^2 = |Ri|^2 - (Ri.u)^2 and (R0 x u).(R1 x u) = R0.R1 - (R0.u)(R1.u) for the unit
+                        // u (Lagrange; |u|^2 is 1 to 2e-7, inside the padding): the Gram entries without
+                        // forming the cross products, and ||M||_F^2 is the sum of the row norms. No clamping:
+                        // a NaN (a light at the origin has a NaN axis) must reach kmax2.
+                        const float ru0 = __builtin_fmaf(m00, b.ux, __builtin_fmaf(m01, b.uy, m02 * b.uz));
+                        const float ru1 = __builtin_fmaf(m10, b.ux, __builtin_fmaf(m11, b.uy, m12 * b.uz));
+                        const float ru2 = __builtin_fmaf(m20, b.ux, __builtin_fmaf(m21, b.uy, m22 * b.uz));
+                        const float n0 = __builtin_fmaf(m00, m00, __builtin_fmaf(m01, m01, m02 * m02));
+                        const float n1 = __builtin_fmaf(m10, m10, __builtin_fmaf(m11, m11, m12 * m12));
+                        const float n2 = __builtin_fmaf(m20, m20, __builtin_fmaf(m21, m21, m22 * m22));
+                        const float r01 = __builtin_fmaf(m00, m10, __builtin_fmaf(m01, m11, m02 * m12));
+                        const float frob2 = n0 + n1 + n2;
                         const float den = L.pos_len - __builtin_amdgcn_sqrtf(frob2) * 1.001f;
-                        const float gaa = a0x * a0x + a0y * a0y + a0z * a0z;
-                        const float gbb = a1x * a1x + a1y * a1y + a1z * a1z;
-                        const float gab = a0x * a1x + a0y * a1y + a0z * a1z;
-                        const float gcc = a2x * a2x + a2y * a2y + a2z * a2z;
+                        const float gaa = __builtin_fmaf(-ru0, ru0, n0);
+                        const float gbb = __builtin_fmaf(-ru1, ru1, n1);
+                        const float gab = __builtin_fmaf(-ru0, ru1, r01);
+                        const float gcc = __builtin_fmaf(-ru2, ru2, n2);
                         const float hd = 0.5f * (gaa - gbb);
                         const float kmax2 = (0.5f * (gaa + gbb) + __builtin_amdgcn_sqrtf(hd * hd + gab * gab)) * 1.001f + gcc;
                         // a light closer to the origin than the matrix can reach has no usable bound
                         const float rden = __builtin_amdgcn_rcpf(den);
                         smax2 = (den > 0.05f * L.pos_len) ? kmax2 * rden * rden * 1.0001f : __builtin_nanf("");
                     }
-                    if (!lit) smax2 = 0.f;
+                    if (!lit || smax2 < 0.f) smax2 = 0.f;   // (the wave maximum compares bit patterns; a NaN passes through)
                     const bool lane_bad = lit && !(smax2 < 0.25f);
                     ok = !__any(lane_bad);
                     const float s2w = uniform(wave_max(smax2));
