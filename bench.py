@@ -112,7 +112,7 @@ def valu_issue(args, world, ms_per_step):
     if world != 1 or (args.width, args.height, args.spheres, args.spp) != (3840, 2160, 1024, 1) or args.no_cull:
         return {}
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_c3_frame_kernel_pmc_summary.json")))
     try:
         with open(files[-1]) as f:
             d = json.load(f)
@@ -138,7 +138,7 @@ def pmc_traffic(args, world):
     if world != 1 or (args.width, args.height, args.spheres, args.spp) != (3840, 2160, 1024, 1) or args.no_cull:
         return None
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_c3_frame_kernel_pmc_summary.json")))
     if not files:
         return None
     try:

@@ -4,7 +4,7 @@ that are committed under profiles/: the rocprofv3 --kernel-trace --stats summary
 as-is, and the per-dispatch PMC averages of the frame kernel with the derived
 figures DESIGN.md / bench.py quote (HBM bytes with the gfx950 FETCH_SIZE x2
 correction of MI355X_MICROARCH.md, VALU issue utilisation, mean occupancy)."""
-import csv, glob, json, os, shutil, sys, collections
+import re, csv, glob, json, os, shutil, sys, collections
 
 tag = sys.argv[1]
 name = sys.argv[2] if len(sys.argv) > 2 else tag
@@ -13,7 +13,10 @@ os.makedirs("profiles", exist_ok=True)
 ks = glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(ks, os.path.join("profiles", f"{name}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(ks)))
-main = max((r for r in rows if "rt_trace_tiles" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
+# the product instantiation (STATS = 0), not the one-off instrumented launch bench.py makes for its work counters
+_cands = [r for r in rows if re.search(r"rt_trace_tiles<\d+, (true|false), 0,", r["Name"])] or \
+         [r for r in rows if "rt_trace_tiles" in r["Name"]]
+main = max(_cands, key=lambda r: float(r["TotalDurationNs"]))
 kname = main["Name"].replace("void (anonymous namespace)::", "").split("(")[0]
 pm = collections.defaultdict(list)
 meta = {}
