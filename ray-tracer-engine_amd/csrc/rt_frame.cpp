@@ -79,7 +79,9 @@ static struct FrameRes {
     uint32_t *h_pixels = nullptr;   // pinned
     int width = 0, height = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;          // device-to-host copies of finished row bands
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t band_done[4] = {nullptr, nullptr, nullptr, nullptr};
     double last_ms = 0.0;
 } fr;
 
@@ -179,8 +181,10 @@ void update()
 
     if (!fr.stream) {
         checkHipErrors(hipStreamCreateWithFlags(&fr.stream, hipStreamNonBlocking));
+        checkHipErrors(hipStreamCreateWithFlags(&fr.copy_stream, hipStreamNonBlocking));
         checkHipErrors(hipEventCreate(&fr.ev0));
         checkHipErrors(hipEventCreate(&fr.ev1));
+        for (hipEvent_t &e : fr.band_done) checkHipErrors(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     if (width != fr.width || height != fr.height) {   // resize between frames keeps working
         release_frame_buffers();
@@ -191,19 +195,35 @@ void update()
         fr.height = height;
     }
 
+    // The frame is rendered in row bands (kernel.cu:1783 is one launch; the bands are the same
+    // pixels) so that the copy of a finished band to the pinned buffer -- a DMA engine's work --
+    // runs while the next band is being rendered: kernel + copy/bands instead of kernel + copy.
+    const int bands = (height >= 512) ? 3 : 1;
     checkHipErrors(hipEventRecord(fr.ev0, fr.stream));
-    const int rc = rt_launch_raytrace(fr.d_pixels, width, height, aspect, objs, lights, light_size, cam, Skybox,
-                                      fr.stream);
-    if (rc != RT_OK) {
-        fprintf(stderr, "update: %s\n", rt_last_error());
-        rt_check(rc, "rt_launch_raytrace", __FILE__, __LINE__);
-        return;
+    for (int k = 0; k < bands; ++k) {
+        const int y0 = (int)((long long)height * k / bands) & ~15, y1 = (k + 1 == bands) ? height : ((int)((long long)height * (k + 1) / bands) & ~15);
+        rt_launch_opts o;
+        memset(&o, 0, sizeof o);
+        o.struct_size = sizeof o;
+        o.cull = -1;
+        o.y0 = y0;
+        o.y1 = y1;
+        uint32_t *band = fr.d_pixels + (size_t)y0 * width;
+        const int rc = rt_launch_raytrace_ex(band, width, height, aspect, objs, lights, light_size, cam, Skybox, fr.stream, &o);
+        if (rc != RT_OK) {
+            fprintf(stderr, "update: %s\n", rt_last_error());
+            rt_check(rc, "rt_launch_raytrace", __FILE__, __LINE__);
+            return;
+        }
+        checkHipErrors(hipGetLastError());                            // kernel.cu:1785
+        checkHipErrors(hipEventRecord(fr.band_done[k], fr.stream));
+        checkHipErrors(hipStreamWaitEvent(fr.copy_stream, fr.band_done[k], 0));
+        checkHipErrors(hipMemcpyAsync(fr.h_pixels + (size_t)y0 * width, band, (size_t)width * (y1 - y0) * sizeof(unsigned int),
+                                      hipMemcpyDeviceToHost, fr.copy_stream));
     }
-    checkHipErrors(hipGetLastError());                                // kernel.cu:1785
     checkHipErrors(hipEventRecord(fr.ev1, fr.stream));
-    checkHipErrors(hipMemcpyAsync(fr.h_pixels, fr.d_pixels, (size_t)width * height * sizeof(unsigned int),
-                                  hipMemcpyDeviceToHost, fr.stream));
-    checkHipErrors(hipStreamSynchronize(fr.stream));                  // kernel.cu:1786
+    checkHipErrors(hipStreamSynchronize(fr.copy_stream));             // kernel.cu:1786 (the stream's kernels precede its copies)
+    checkHipErrors(hipStreamSynchronize(fr.stream));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, fr.ev0, fr.ev1) == hipSuccess) fr.last_ms = ms;
 
