@@ -457,5 +457,8 @@ def test_packed24_is_the_packed_frame_without_its_zero_byte(rt, gpu):
         wide = rd.unpack_rgb24(out["packed24"], 160)
         assert torch.equal(wide, out["packed"]), kw
         assert int((out["packed"].view(torch.uint8).view(-1, 4)[:, 3] != 0).sum()) == 0
+    out = sc.render(164, 40, want_packed24=True)   # a multiple of 4 but not of the tile width
+    torch.cuda.synchronize()
+    assert torch.equal(rd.unpack_rgb24(out["packed24"], 164), out["packed"])
     with pytest.raises(rt.RtError):
         sc.render(162, 40, want_packed24=True)
