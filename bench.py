@@ -2,20 +2,28 @@
 """bench.py -- headline benchmark of the ray-tracing hot path on MI355X.
 
 Metric (BASELINE.json): primary Mrays/s (+ frames/s) at 3840x2160, 1024 spheres,
-1 spp, on 1/2/4/8 GPUs. One "step" = one frame: every rank renders its
-contiguous row band with one HIP kernel launch (float4 linear-colour buffer +
-packed 0x00RRGGBB buffer, both resident in HBM), then -- for N > 1 -- a single
-RCCL gather of the packed bands to rank 0 reassembles the image.
+1 spp, on 1/2/4/8 GPUs. One "step" = one complete frame with inputs and outputs
+resident in HBM: every rank renders its rows with one HIP kernel launch (float4
+linear-colour buffer + packed 0x00RRGGBB buffer), then -- for N > 1 -- a single
+RCCL gather of the packed rows to rank 0 reassembles the image.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line. Besides the contract fields it carries
-  roofline      HBM-write roofline of the frame kernel (the roof north_star names),
-  roofline_valu the roof that actually binds (fp32 VALU),
-  cpu_baseline  the CPU oracle timed on this box's cores on a bounded row sample
-                (rank 0, N=1 only), with GPU-vs-CPU parity checked on those rows.
+Rank 0 prints ONE JSON line. `value` comes from the strictly SERIAL loop at N = 1 (one
+frame at a time on one stream; static camera, every table cached); everything else that
+was measured in the same run is reported next to it under its own key:
+  roofline         HBM roofline of the frame kernel: algorithmic bytes / the kernel's launch
+                   duration (HIP events on the launch stream, serial loop) / 8 TB/s
+  roofline_valu    the roof that binds (vector-instruction issue)
+  moving_camera    the same loop with the camera nudged every frame, as the reference's
+                   checkKey() does (kernel.cu:1716-1764): eye-cone table rebuilt per frame
+  pipelined        two frames in flight on two streams (fill/drain of a launch overlapped)
+  update_end_to_end  frames through rt_update(): kernel + D2H of the packed frame +
+                   setPixelBuff memcpy, what the reference's boundary requires per frame
+  cpu_baseline     the CPU oracle timed on this box's cores (all cores and one thread) on a
+                   bounded row sample, with GPU-vs-CPU parity checked on those rows
 """
 import argparse
 import json
@@ -49,7 +57,9 @@ def parse():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--tile", type=int, default=0, help="tile width 8/16/32/64 (0 = library default)")
     ap.add_argument("--no-cull", action="store_true", help="brute-force loops exactly as the reference")
+    ap.add_argument("--table-lds", action="store_true", help="stage the whole sphere table in LDS per workgroup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the moving-camera / pipelined / update() legs")
     ap.add_argument("--cpu-band-stride", type=int, default=8,
                     help="CPU baseline renders every k-th 8-row band of the frame")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline")
@@ -59,17 +69,29 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--gather-words", type=int, default=24, choices=[24, 32],
                     help="N > 1: bits per pixel a rank sends to the root (24: packed word without its zero byte)")
-    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2],
-                    help="consecutive frames alternate between this many HIP streams, each with its own "
-                         "framebuffers (2: one frame's last waves overlap the next frame's first)")
+    ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2],
+                    help="timed loop: 1 = strictly serial (default at N = 1), 2 = consecutive frames alternate "
+                         "between two HIP streams with their own framebuffers (default at N > 1, where frame i's "
+                         "gather overlaps frame i+1's kernel)")
     return ap.parse_args()
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(rt, scene, args, gpu_rgba, gpu_packed):
     """Time the CPU oracle (kind 'port': the C restatement of the reference's
-    kernel) on a deterministic row sample of the SAME workload with every host
-    core, and check the GPU frame against it on those rows. bench.py's
-    cpu_baseline leg is one of the three places allowed to touch oracle/."""
+    kernel) on a deterministic row sample of the SAME workload -- with every host
+    core, and with one thread on a smaller sample -- and check the GPU frame against it
+    on those rows. bench.py's cpu_baseline leg is one of the three places allowed to touch oracle/."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py
     try:
@@ -78,64 +100,47 @@ def cpu_baseline(rt, scene, args, gpu_rgba, gpu_packed):
         cores = os.cpu_count() or 1
     cores = min(cores, args.cpu_threads)      # a 1-GPU box's CPU share is 16 cores
     w, h = args.width, args.height
+
+    def run(bands, nthreads, check):
+        rows = tests = mismatched = 0
+        t_total = 0.0
+        for y0 in bands:
+            y1 = min(y0 + 8, h)
+            t0 = time.perf_counter()
+            rgba, packed, cnt = oracle_py.render(scene.spheres, scene.n_spheres, scene.texture, scene.sky, scene.sky_box,
+                                                 scene.lights, scene.n_lights, rt.default_camera(), w, h,
+                                                 rt.default_aspect(), y0=y0, y1=y1, nthreads=nthreads)
+            t_total += time.perf_counter() - t0
+            rows += y1 - y0
+            tests += cnt["primary_tests"] + cnt["shadow_tests"]
+            if check and gpu_rgba is not None:
+                mismatched += int((rgba.view(np.uint32) != gpu_rgba[y0:y1].view(np.uint32)).any(axis=2).sum())
+                mismatched += int((packed != gpu_packed[y0:y1]).sum())
+        return rows, tests, mismatched, t_total
+
     bands = list(range(0, h, 8 * args.cpu_band_stride))
-    rows = 0
-    tests = 0
-    mismatched = 0
-    t_total = 0.0
-    for y0 in bands:
-        y1 = min(y0 + 8, h)
-        t0 = time.perf_counter()
-        rgba, packed, cnt = oracle_py.render(scene.spheres, scene.n_spheres, scene.texture, scene.sky, scene.sky_box,
-                                             scene.lights, scene.n_lights, rt.default_camera(), w, h,
-                                             rt.default_aspect(), y0=y0, y1=y1, nthreads=cores)
-        t_total += time.perf_counter() - t0
-        rows += y1 - y0
-        tests += cnt["primary_tests"] + cnt["shadow_tests"]
-        if gpu_rgba is not None:
-            mismatched += int((rgba.view(np.uint32) != gpu_rgba[y0:y1].view(np.uint32)).any(axis=2).sum())
-            mismatched += int((packed != gpu_packed[y0:y1]).sum())
+    rows, tests, mismatched, t_total = run(bands, cores, True)
     rays = rows * w
+    one = bands[len(bands) // 2: len(bands) // 2 + 1]          # one 8-row band in the middle of the frame
+    rows1, _, _, t1 = run(one, 1, False)
     return {
         "value": rays / t_total / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "cpu_model": cpu_model(),
         "sample": f"every {args.cpu_band_stride}th 8-row band of the {w}x{h}/{args.spheres}-sphere frame "
                   f"({rows} rows, {rays} rays, {t_total:.1f} s)",
+        "single_thread": {"value": rows1 * w / t1 / 1e6, "unit": "Mrays/s", "cores": 1,
+                          "sample": f"rows {one[0]}..{one[0] + rows1 - 1} ({rows1 * w} rays, {t1:.1f} s)"},
         "tests_per_ray": tests / rays,
         "gpu_vs_cpu_mismatched_pixels": mismatched if gpu_rgba is not None else None,
     }
 
 
-def valu_issue(args, world, ms_per_step):
-    """VALU instruction issue rate against the plain-op issue rate measured on this chip
-    (tools/ubench/valu_rate.hip: 1.05 ns per wave64 v_mul/v_add per SIMD, profiles/r01_valu_issue_rates.txt).
-    Instructions per wave come from the committed PMC pass (SQ_INSTS_VALU), the time is this run's."""
-    if world != 1 or (args.width, args.height, args.spheres, args.spp) != (3840, 2160, 1024, 1) or args.no_cull:
-        return {}
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_c3_frame_kernel_pmc_summary.json")))
-    try:
-        with open(files[-1]) as f:
-            d = json.load(f)
-        per_wave = d["derived"]["valu_insts_per_wave"]
-        waves = d["pmc_avg_per_dispatch"]["SQ_WAVES"]
-    except Exception:
-        return {}
-    simds = 256 * 4
-    rate = per_wave * waves / simds / (ms_per_step * 1e-3)          # VALU instructions per second per SIMD
-    peak = 1.0 / 1.05e-9
-    return {"valu_insts_per_wave_pmc": per_wave, "valu_issue_rate_per_simd_Ginst_s": rate / 1e9,
-            "valu_issue_peak_per_simd_Ginst_s": peak / 1e9, "valu_issue_frac": rate / peak,
-            "valu_issue_note": "plain fp32 ops issue at 0.95 G/s per SIMD; compares, selects, binary64, division "
-                               "helpers take 1.7x and transcendentals 3.3x that slot, so the pipe is busier than "
-                               "this fraction (DESIGN.md section 4, roofline)"}
-
-
-def pmc_traffic(args, world):
-    """HBM bytes per launch of the frame kernel from the committed rocprofv3 PMC
-    passes (profiles/*_pmc_summary.json; FETCH_SIZE x2 + WRITE_SIZE as
-    MI355X_MICROARCH.md prescribes). bench.py cannot collect counters itself;
-    the number applies to the default C3 single-GPU configuration only."""
-    if world != 1 or (args.width, args.height, args.spheres, args.spp) != (3840, 2160, 1024, 1) or args.no_cull:
+def committed_pmc(args, world):
+    """Counters bench.py cannot collect itself, from the newest committed rocprofv3 PMC pass of this
+    configuration (profiles/*_c3_frame_kernel_pmc_summary.json; FETCH_SIZE x2 + WRITE_SIZE as
+    MI355X_MICROARCH.md prescribes). Applies to the default C3 single-GPU configuration only."""
+    if world != 1 or (args.width, args.height, args.spheres, args.spp) != (3840, 2160, 1024, 1) or args.no_cull \
+            or args.table_lds or args.tile not in (0, 8):
         return None
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_c3_frame_kernel_pmc_summary.json")))
@@ -143,9 +148,25 @@ def pmc_traffic(args, world):
         return None
     try:
         with open(files[-1]) as f:
-            return json.load(f)["derived"].get("hbm_traffic_bytes")
+            d = json.load(f)
+        d["file"] = os.path.basename(files[-1])
+        return d
     except Exception:
         return None
+
+
+def timed_loop(step, steps, warmup, sync, world):
+    k = 0
+    for _ in range(warmup):
+        step(k, None)
+        k += 1
+    sync(k)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(k, i)
+        k += 1
+    sync(k)
+    return time.perf_counter() - t0, k
 
 
 def main():
@@ -185,11 +206,10 @@ def main():
         y0, y1 = 0, h
         rows = max_rows = h
         interleave = None
+    nfl = args.frames_in_flight or (1 if world == 1 else 2)
 
-    # outputs resident in HBM: float4 linear colour + packed words, band-local. Two sets:
-    # frames alternate between them (and between two streams when --frames-in-flight 2), so
-    # that frame i's last waves -- and, for N > 1, its gather -- overlap frame i+1's kernel.
-    nfl = args.frames_in_flight
+    # outputs resident in HBM: float4 linear colour + packed words, band-local. Two sets: with two
+    # frames in flight consecutive frames alternate between them (and between two streams).
     rgb24 = world > 1 and args.gather_words == 24 and w % 4 == 0
     rgba2 = [torch.empty((rows, w, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
     packed2 = [torch.zeros((max_rows, w), dtype=torch.int32, device="cuda") for _ in range(2)]
@@ -201,15 +221,17 @@ def main():
     gathered2 = [roots[0].views, roots[1].views] if roots else [None, None]
     frame = None
     main_stream = torch.cuda.current_stream()
-    streams = [torch.cuda.Stream() for _ in range(2)] if nfl == 2 else [main_stream, main_stream]
-    fds = [scene.frame_desc(w, h, pixels=packed2[b].data_ptr(), rgba=rgba2[b].data_ptr(), y0=y0, y1=y1, spp=args.spp,
-                            cull=not args.no_cull, tile=args.tile, interleave=interleave,
-                            packed24=send2[b].data_ptr() if rgb24 else 0) for b in range(2)]
+    two_streams = [torch.cuda.Stream() for _ in range(2)]
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    def make_fd(b, cam=None):
+        return scene.frame_desc(w, h, pixels=packed2[b].data_ptr(), rgba=rgba2[b].data_ptr(), y0=y0, y1=y1, spp=args.spp,
+                                cull=not args.no_cull, tile=args.tile, interleave=interleave, cam=cam,
+                                packed24=send2[b].data_ptr() if rgb24 else 0, table_lds=args.table_lds)
+
+    fds = [make_fd(b) for b in range(2)]
     pending = [None, None]
 
-    def finish(b):
+    def finish(b, streams):
         """Complete frame b's gather and, on the root, put the rows in place (on b's stream)."""
         if pending[b] is not None:
             with torch.cuda.stream(streams[b]):
@@ -219,51 +241,76 @@ def main():
                     nonlocal frame
                     frame = roots[b].assemble()       # one index_select puts every row in place
 
-    def step(k, i=None):
-        b = k & 1
-        if world > 1:
-            finish(b)                      # buffer set b is free again
-        with torch.cuda.stream(streams[b]):
-            if i is not None:
-                ev[i][0].record(streams[b])
-            scene.render_raw(fds[b], streams[b].cuda_stream)
-            if i is not None:
-                ev[i][1].record(streams[b])
-            if world > 1:                  # the frame's single collective, asynchronous, ordered after b's kernel
-                src = send2[b] if coll_dev == "cuda" else send2[b].cpu()
-                if rank == 0:
-                    pending[b] = dist.gather(src, gathered2[b], dst=0, async_op=True)
-                else:
-                    pending[b] = dist.gather(src, None, dst=0, async_op=True)
+    def make_step(streams, ev, fd_of):
+        def step(k, i):
+            b = k & 1
+            if world > 1:
+                finish(b, streams)             # buffer set b is free again
+            with torch.cuda.stream(streams[b]):
+                if i is not None and ev is not None:
+                    ev[i][0].record(streams[b])
+                scene.render_raw(fd_of(k, b), streams[b].cuda_stream)
+                if i is not None and ev is not None:
+                    ev[i][1].record(streams[b])
+                if world > 1:                  # the frame's single collective, asynchronous, ordered after b's kernel
+                    src = send2[b] if coll_dev == "cuda" else send2[b].cpu()
+                    if rank == 0:
+                        pending[b] = dist.gather(src, gathered2[b], dst=0, async_op=True)
+                    else:
+                        pending[b] = dist.gather(src, None, dst=0, async_op=True)
+        return step
 
-    k = 0
-    for _ in range(args.warmup):
-        step(k)
-        k += 1
-    if world > 1:
-        finish(0)
-        finish(1)
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(k, i)
-        k += 1
-    if world > 1:
-        finish(k & 1)
-        finish((k + 1) & 1)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    def make_sync(streams):
+        def sync(k):
+            if world > 1:
+                finish(k & 1, streams)
+                finish((k + 1) & 1, streams)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+        return sync
+
+    def reduce_max(*vals):
+        t = torch.tensor(list(vals), dtype=torch.float64, device=coll_dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t]
+
+    # ---------------- the timed loop the contract asks for ----------------
+    streams = two_streams if nfl == 2 else [main_stream, main_stream]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    elapsed, k = timed_loop(make_step(streams, ev, lambda k, b: fds[b]), args.steps, args.warmup, make_sync(streams), world)
     packed = packed2[(k - 1) & 1]
     rgba = rgba2[(k - 1) & 1]
-
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=coll_dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, kernel_ms_max = float(t[0]), float(t[1])
+    elapsed, kernel_ms = reduce_max(elapsed, kernel_ms)
+    ms_per_step = elapsed / args.steps * 1e3
+
+    extras = {}
+    if not args.no_extras:
+        # camera nudged every frame (kernel.cu:1727 `cam.Org.z += 0.1`, back and forth so the view stays
+        # the workload's): the eye-cone table is rebuilt on the device for every frame
+        def cam_of(k):
+            cam = rt.default_camera()
+            cam.Org.z = 10.0 + 0.1 * ((k % 8) - 4 if (k // 8) % 2 == 0 else 4 - (k % 8))
+            return cam
+        s1 = [main_stream, main_stream]
+        e_mv, _ = timed_loop(make_step(s1, None, lambda k, b: make_fd(b, cam_of(k))), args.steps, args.warmup, make_sync(s1), world)
+        e_st, _ = timed_loop(make_step(s1, None, lambda k, b: fds[b]), args.steps, args.warmup, make_sync(s1), world)
+        e_pl, _ = timed_loop(make_step(two_streams, None, lambda k, b: fds[b]), args.steps, args.warmup, make_sync(two_streams), world)
+        e_mv, e_st, e_pl = reduce_max(e_mv, e_st, e_pl)
+        rays = w * h * args.spp
+        extras["moving_camera"] = {"ms_per_step": e_mv / args.steps * 1e3, "Mrays_per_s": rays / (e_mv / args.steps) / 1e6,
+                                   "static_camera_same_loop_ms": e_st / args.steps * 1e3,
+                                   "overhead_vs_static": e_mv / e_st - 1.0,
+                                   "note": "one frame at a time, cam.Org.z nudged by 0.1 every frame (kernel.cu:1727); eye-cone table "
+                                           "rebuilt by a device kernel on the frame's stream, no host synchronisation"}
+        extras["pipelined"] = {"frames_in_flight": 2, "ms_per_step": e_pl / args.steps * 1e3,
+                               "Mrays_per_s": rays / (e_pl / args.steps) / 1e6,
+                               "note": "consecutive frames alternate between two HIP streams with their own framebuffers"}
+        # restore the last static frame in buffer set of `packed` for the parity check below
+        scene.render_raw(fds[(k - 1) & 1], main_stream.cuda_stream)
+        torch.cuda.synchronize()
 
     # executed-work statistics from the instrumented kernel variant (untimed)
     stats = scene.render(w, h, y0=y0, y1=y1, want_stats=True, spp=args.spp, cull=not args.no_cull, tile=args.tile,
@@ -274,13 +321,32 @@ def main():
     stats = dict(zip(rt.STAT_NAMES, [float(v) for v in st.cpu()]))
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
         rays = w * h * args.spp
         value = rays / (ms_per_step * 1e-3) / 1e6
-        band_bytes = rows * w * (16 + 4 + (3 if rgb24 else 0)) * 1.0   # algorithmic bytes of one launch: float4 + packed word (+ 24-bit copy for the gather) per pixel
-        achieved = band_bytes / (kernel_ms * 1e-3) / 1e9
+        # algorithmic bytes of one launch: float4 + packed word (+ 24-bit copy for the gather) per pixel-sample
+        band_bytes = rows * w * (16 + 4 + (3 if rgb24 else 0)) * 1.0
+        # the launch's duration: HIP events on its stream. With two frames in flight an event pair spans two
+        # overlapped kernels, so the per-frame time is the honest denominator there.
+        launch_ms = kernel_ms if nfl == 1 else ms_per_step
+        achieved = band_bytes / (launch_ms * 1e-3) / 1e9
         slots = stats["wave_test_slots"] + stats["cull_tests"]     # lane slots issued for sphere/beam tests
         valu_tflops = slots * FLOP_PER_TEST / (ms_per_step * 1e-3) / 1e12
+        pmc = committed_pmc(args, world)
+        valu = {}
+        if pmc:
+            try:
+                per_wave = pmc["derived"]["valu_insts_per_wave"]
+                waves = pmc["pmc_avg_per_dispatch"]["SQ_WAVES"]
+                rate = per_wave * waves / (256 * 4) / (launch_ms * 1e-3)      # VALU instructions / s / SIMD
+                valu = {"valu_insts_per_wave_pmc": per_wave, "salu_insts_per_wave_pmc": pmc["derived"].get("salu_insts_per_wave"),
+                        "pmc_file": pmc["file"],
+                        "valu_issue_rate_per_simd_Ginst_s": rate / 1e9, "valu_issue_nominal_per_simd_Ginst_s": 1.2,
+                        "valu_issue_frac_of_nominal": rate / 1.2e9,
+                        "note_issue": "nominal = one wave64 instruction per 2 cycles per SIMD at 2.4 GHz; plain fp32 ops reach "
+                                      "0.95 G/s on this chip, compares/selects/binary64 0.55, transcendentals 0.29 "
+                                      "(profiles/r01_valu_issue_rates.txt)"}
+            except Exception:
+                valu = {}
         out = {
             "metric": "primary_Mrays_per_s", "value": value, "unit": "Mrays/s",
             "frames_per_s": 1e3 / ms_per_step,
@@ -288,8 +354,10 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C3: {w}x{h}, {args.spheres} spheres (MSVC rand() replay seed {args.seed}), "
-                                   f"{args.spp} spp, 3 lights x 10 shadow samples, LDS sphere-tile staging on "
-                                   f"(per-tile survivor lists; RT_TABLE_LDS=1 stages the whole table instead)",
+                                   f"{args.spp} spp, 3 lights x 10 shadow samples; static camera, one wave64 per 8x8 tile, "
+                                   f"each tile's culled sphere lists staged in LDS and broadcast across lanes "
+                                   + ("(whole table staged in LDS per workgroup)" if args.table_lds else
+                                      "(the 16 KiB tables themselves are read from L2; opts.table_lds stages them whole)"),
                        "cull": not args.no_cull, "tile": args.tile or 8,
                        "parallelism": f"{BLOCK}-row blocks round-robin x{world} + 1 RCCL gather per frame of "
                                       f"{24 if rgb24 else 32}-bit pixels (overlapped with the next frame's kernel)"
@@ -298,25 +366,26 @@ def main():
                        "outputs": "float4 RGBA + packed 0x00RRGGBB in HBM"},
             "kernel_ms": kernel_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, world),
-                         "algorithmic_bytes_per_launch": band_bytes,
-                         "achieved_chip": nfl * achieved,
-                         "note": "HBM is NOT the binding roof for this path (SURVEY.md F2); see roofline_valu. "
-                                 + ("Two frames are in flight on two streams: a launch's duration (kernel_ms, HIP "
-                                    "events on its stream) spans two overlapped kernels, so the chip moves "
-                                    "achieved_chip = 2 x achieved; per-frame time is ms_per_step."
-                                    if nfl == 2 else "One frame in flight.")},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["derived"].get("hbm_traffic_bytes") if pmc else None,
+                         "algorithmic_bytes_per_launch": band_bytes, "launch_ms": launch_ms,
+                         "note": "achieved = algorithmic_bytes_per_launch / launch_ms; launch_ms = mean HIP-event duration of the "
+                                 "frame kernel on its stream in this run's serial loop"
+                                 + ("" if nfl == 1 else " (two frames in flight: time per frame instead)")
+                                 + ". HBM is NOT the binding roof for this path (SURVEY.md F2); see roofline_valu."},
             "roofline_valu": {"bound": "valu_fp32", "achieved": valu_tflops, "peak": VALU_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": valu_tflops / VALU_PEAK_TFLOPS,
                               "executed_test_slots": slots,
                               "note": "64-lane issue slots of sphere + beam tests x 17 flop / frame time; "
                                       "excludes ray setup and shading ALU work (most of the instructions)",
-                              **valu_issue(args, world, ms_per_step)},
+                              **valu},
             "work": {"hit_fraction": stats["hit_pixels"] / rays, "primary_lane_tests_per_ray": stats["primary_tests"] / rays,
                      "shadow_lane_tests_per_ray": stats["shadow_tests"] / rays,
                      "cull_tests_per_ray": stats["cull_tests"] / rays,
                      "list_overflows": stats["list_overflows"]},
+            **extras,
         }
+        if world == 1 and not args.no_extras and (w, h, args.spp) == (3840, 2160, 1) and not args.no_cull:
+            out["update_end_to_end"] = update_end_to_end(rt, args, packed[:rows])
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.synchronize()
             g_rgba = rgba.cpu().numpy() if args.spp == 1 else None
@@ -328,12 +397,47 @@ def main():
             out["work"]["algorithmic_rate_TFLOPs"] = brute_tests * FLOP_PER_TEST / (ms_per_step * 1e-3) / 1e12
             out["work"]["executed_over_brute_force"] = slots / brute_tests
         if world > 1:
-            idx = torch.as_tensor(my_rows, device=frame.device)
+            # the assembled frame against a full single-GPU render of the same frame (untimed, rank 0)
+            full = scene.render(w, h, spp=args.spp, cull=not args.no_cull, tile=args.tile, want_rgba=False)["packed"]
+            torch.cuda.synchronize()
             out["gathered_frame_shape"] = list(frame.shape)
-            out["gathered_rank0_rows_ok"] = bool(torch.equal(frame[idx], packed[:rows].to(frame.device)))
+            out["gathered_frame_equals_single_gpu_render"] = bool(torch.equal(frame.to(full.device), full))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def update_end_to_end(rt, args, packed_ref):
+    """Frames through the reference's own boundary: rt_update() = size query -> launch(es) -> D2H of the packed
+    frame into pinned memory -> setPixelBuff memcpy into the offscreen window (kernel.cu:1762-1792)."""
+    import ctypes as C
+    lib = rt.load_library()
+    lib.rt_config_set_sphere_count(args.spheres)
+    lib.rt_config_set_seed(args.seed)
+    lib.rt_on_start()
+    lib.rt_offscreen_resize(args.width, args.height)
+    n = max(5, min(30, args.steps))
+    for _ in range(3):
+        lib.rt_update()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        lib.rt_update()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    got = np.ctypeslib.as_array(lib.rt_offscreen_pixels(), shape=(args.height, args.width))
+    same = bool(np.array_equal(got.view(np.uint32), packed_ref.cpu().numpy().view(np.uint32)))
+    # the same with the camera moved before every frame
+    cam = lib.rt_config_camera()
+    t0 = time.perf_counter()
+    for i in range(n):
+        cam.contents.Org.z = 10.0 + (0.1 if i % 2 else 0.0)
+        lib.rt_update()
+    ms_mv = (time.perf_counter() - t0) / n * 1e3
+    cam.contents.Org.z = 10.0
+    return {"ms_per_frame": ms, "frames_per_s": 1e3 / ms, "frames": n, "presented_frame_equals_kernel_frame": same,
+            "moving_camera_ms_per_frame": ms_mv,
+            "device_ms_last_frame": float(lib.rt_last_frame_ms()),
+            "note": "host wall clock around rt_update(): kernel in 3 row bands + D2H of 33 MB into pinned memory "
+                    "(overlapped band by band) + setPixelBuff memcpy; PCIe-inclusive, never the bench `value`"}
 
 
 if __name__ == "__main__":

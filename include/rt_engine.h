@@ -182,7 +182,8 @@ typedef struct rt_launch_opts {
     uint64_t *stats;         /* optional device array of RT_STATS_COUNT counters      */
     int force_slow_path;     /* testing: disable every exactness-preserving shortcut  */
     int profile;             /* diagnostics: with `stats`, fill the per-phase cycle
-                                counters (RT_STAT_PHASE0..) instead of work counters   */
+                                counters (RT_STAT_PHASE0..) instead of work counters;
+                                tuning builds of the library only (-DRT_TUNING)        */
     int interleave_count;    /* multi-GPU load balance: when > 1 this call renders the
                                 row blocks k = interleave_index, +count, +2*count, ... of
                                 `interleave_rows` rows each (y0/y1 must be 0). Output
@@ -194,6 +195,11 @@ typedef struct rt_launch_opts {
                                 word without its zero top byte), width*rows*3 bytes, band-local
                                 like `pixels`; needs width % 4 == 0. What a multi-GPU rank
                                 sends to the root: a quarter less than the 32-bit words      */
+    int table_lds;           /* 1: each 256-thread workgroup stages the WHOLE sphere table in LDS
+                                (north_star's first design) instead of reading it from global
+                                memory / L2 and keeping only the tiles' survivor lists in LDS.
+                                Same pixels; measured slower, so opt-in.
+                                Default tile only; ignored when the table does not fit          */
 } rt_launch_opts;
 
 enum { RT_STAT_PRIMARY_TESTS = 0, /* sphere tests issued for primary rays (per lane) */
@@ -236,6 +242,11 @@ void rt_update(void);        /* one frame: size query -> launch -> sync -> setPi
 /* Scene knobs the reference keeps as compile-time globals (kernel.cu:1231,1695-1702). */
 int rt_config_set_sphere_count(int n);       /* before rt_on_start(); default 1024    */
 int rt_config_set_seed(unsigned int seed);   /* MSVC rand() seed; default 1           */
+/* Asset files of onStart() (kernel.cu:1700,1706 and loadMesh :1181 hard-code C:\ paths): binary
+ * PPM (P6) textures and an OBJ mesh. NULL / "" = not set: onStart() then looks at the
+ * application's environment (RT_OBJECT_TEXTURE, RT_SKY_TEXTURE, RT_MESH_OBJ), and without
+ * those uses the synthetic textures and no mesh. Call before rt_on_start().                  */
+int rt_config_set_assets(const char *object_texture, const char *sky_texture, const char *mesh_obj);
 rt_camera *rt_config_camera(void);           /* the global `cam` (kernel.cu:1695)     */
 rt_light *rt_config_lights(int *count);      /* the global `lights` (kernel.cu:1694)  */
 float rt_default_aspect(void);               /* (float)tan(90*0.5*3.1415/180), :1701  */
@@ -319,7 +330,13 @@ int rt_scene_render(rt_scene *s, const rt_frame_desc *fd, void *stream);
 typedef struct rt_frame_graph rt_frame_graph;
 rt_frame_graph *rt_graph_capture(rt_scene *s, const rt_frame_desc *fd, int passes,
                                  uint32_t *host_pixels /* pinned, may be NULL */, void *stream);
+/* Replays the frame. If the scene's tables were rewritten since the graph was built (another
+ * sphere list, lights, textures, or a direct render at another resolution) the graph is
+ * rebuilt first -- it never replays against tables it was not built for.                     */
 int rt_graph_launch(rt_frame_graph *g, void *stream);
+/* A camera move (kernel.cu:1716-1759 moves `cam` every frame): the kernel nodes' by-value
+ * uniforms are replaced with hipGraphExecKernelNodeSetParams and the eye-cone table is rebuilt
+ * by a kernel node of the graph itself -- no re-capture, no synchronisation.                  */
 int rt_graph_set_camera(rt_frame_graph *g, const rt_camera *cam);
 void rt_graph_destroy(rt_frame_graph *g);
 
@@ -341,6 +358,15 @@ int rt_debug_intersect(const rt_sphere *spheres, const rt_ray *rays, int n, int 
 int rt_debug_light(const rt_sphere *spheres, int n_spheres, const rt_vec3 *start,
                    const rt_vec3 *normal, const rt_light *light, int n,
                    float *dirs /* n*30 */, float *brightness /* n */);
+/* The culling kernels' shortcuts against the long forms they stand for, evaluated on the
+ * device for n pseudo-random inputs derived from `seed` (tests only):
+ *  what 0: lean normalise vs the IEEE one on vectors of every scale -> out[0] = differing results
+ *  what 1: lean sqrt vs IEEE sqrtf on EVERY float in [2^-96, 2^40] (n, seed ignored) -> out[0] = differing results
+ *  what 2: approximate (tx, ty) of a unit normal vs the exact binary64 expressions of
+ *          kernel.cu:1402-1403 -> out[0], out[1] = max |error| of tx, ty (as float bits in the
+ *          low word), out[2] = lanes the 512x512 certainty test accepted, out[3] = accepted
+ *          lanes whose texel index differs from the exact one (must be 0)                   */
+int rt_debug_shortcuts(int what, unsigned seed, long long n, unsigned long long out[4]);
 
 #ifdef __cplusplus
 }

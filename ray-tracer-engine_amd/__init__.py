@@ -123,7 +123,7 @@ class LaunchOpts(C.Structure):
                 ("accumulate", C.c_int), ("resolve", C.c_int), ("cull", C.c_int), ("tile", C.c_int),
                 ("stats", C.c_void_p), ("force_slow_path", C.c_int), ("profile", C.c_int),
                 ("interleave_count", C.c_int), ("interleave_index", C.c_int), ("interleave_rows", C.c_int),
-                ("packed24", C.c_void_p)]
+                ("packed24", C.c_void_p), ("table_lds", C.c_int)]
 
 
 class FrameDesc(C.Structure):
@@ -163,6 +163,7 @@ def load_library():
         "rt_update": (None, []),
         "rt_config_set_sphere_count": (ci, [ci]),
         "rt_config_set_seed": (ci, [C.c_uint]),
+        "rt_config_set_assets": (ci, [C.c_char_p, C.c_char_p, C.c_char_p]),
         "rt_config_camera": (C.POINTER(Camera), []),
         "rt_config_lights": (C.POINTER(Light), [C.POINTER(ci)]),
         "rt_default_aspect": (cf, []),
@@ -202,6 +203,7 @@ def load_library():
         "rt_debug_math": (ci, [ci, fp, fp, fp, ci]),
         "rt_debug_intersect": (ci, [C.POINTER(Sphere), C.POINTER(Ray), ci, C.POINTER(ci), fp]),
         "rt_debug_light": (ci, [C.POINTER(Sphere), ci, C.POINTER(Vec3), C.POINTER(Vec3), C.POINTER(Light), ci, fp, fp]),
+        "rt_debug_shortcuts": (ci, [ci, C.c_uint, C.c_longlong, C.POINTER(C.c_ulonglong)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError here = header/library mismatch: fail loudly
@@ -362,7 +364,7 @@ class Scene:
 
     def frame_desc(self, width, height, *, pixels=0, rgba=0, cam=None, aspect=None, y0=0, y1=0, spp=1,
                    sample_base=0, sample_total=0, accumulate=False, resolve=0, cull=True, tile=0,
-                   stats=0, force_slow=False, profile=False, interleave=None, packed24=0) -> FrameDesc:
+                   stats=0, force_slow=False, profile=False, interleave=None, packed24=0, table_lds=False) -> FrameDesc:
         fd = FrameDesc()
         fd.struct_size = C.sizeof(FrameDesc)
         fd.width, fd.height = width, height
@@ -384,6 +386,7 @@ class Scene:
         if interleave is not None:          # (count, index, block_rows)
             o.interleave_count, o.interleave_index, o.interleave_rows = interleave
         o.packed24 = packed24
+        o.table_lds = 1 if table_lds else 0
         return fd
 
     def render_raw(self, fd: FrameDesc, stream=0):

@@ -21,6 +21,10 @@
                                // (HBM writes = the 166 MB of pixels); 6 -> 1.43 ms but spills
                                // that add 0.6 GB of scratch writes per frame.
 #endif
+#ifndef RT_MIN_WAVES_ONE_SAMPLE
+#define RT_MIN_WAVES_ONE_SAMPLE 6 // the one-sample kernels without a mesh (every BASELINE config at 1 spp, and each pass of the
+                               // hipGraph frame) fit 80 registers without a spill: 6 waves per SIMD
+#endif
 #ifndef RT_WAVES_PER_WG
 #define RT_WAVES_PER_WG 4         // wave tiles per workgroup when the table is staged in LDS (1, 2 or 4)
 #endif
@@ -62,70 +66,19 @@ struct RtBoxDev {       // one leaf of the flat BVH: bounds + its slice of the i
     int start, len;
 };
 
-struct RtFrameConsts {
-    // frame / band geometry
-    int width, height;          // full frame (ray generation uses these)
-    int y0, y1;                 // rows rendered by this launch
-    int n_spheres, n_lights;
-    int spp, sample_base;       // samples taken by this launch, index of the first
-    float inv_sample_total_unused_;
-    float sample_total;         // divisor at resolve time, as float
-    int accumulate, resolve;
-    int force_slow;
-    int ablate;                 // diagnostics only (RT_ABLATE env): skip parts of the kernel to price them
-    int il_count, il_index, il_rows;   // interleaved row blocks (multi-GPU); il_count <= 1: contiguous band
-    int local_rows;             // rows rendered by this launch (= y1 - y0 for a contiguous band)
-
-    // primary-ray uniforms (kernel.cu:1624-1631, 248-258)
-    double aspect_d;            // (double)aspect
-    double width_d, height_d;   // (double)(float)width, (double)(float)height
-    double hw_d;                // (double)((float)height / width)
-    float eye_nz;               // -( -1/aspect ) : z component of (dir - eyePos)
-    float org_x, org_y, org_z;  // eyePos + cam.Org
-    float cos_pitch, sin_pitch, cos_yaw, sin_yaw;
-    double off_x[RT_DEV_MAX_SPP], off_y[RT_DEV_MAX_SPP];
-
-    // shadow-sample uniforms (kernel.cu:1453-1454, 1462-1463, 1538)
+// Frame data the kernel reads rarely or from inside its loops only: lights, shadow-sample
+// constants, sky, the few planes/cubes, the mesh. It lives in DEVICE memory behind
+// RtFrameConsts::aux (re-uploaded only when its content changes -- a camera move does not
+// touch it), so that none of it competes for the SGPR file with the frame uniforms the whole
+// kernel uses (by value, the 70 SGPR spills of round 1 came from there).
+struct RtFrameAux {
+    // shadow-sample uniforms (kernel.cu:1453-1454, 1462-1463)
     float jf[RT_SHADOW_SAMPLES];      // (float)j / 10
     float jcos[RT_SHADOW_SAMPLES];    // cosf(phi_j), phi_j = (float)j/10 * 2.f * 3.1415f
     float jsin[RT_SHADOW_SAMPLES];    // sinf(phi_j)
-    float btab[RT_SHADOW_SAMPLES + 1];// b after n `b += 0.1` steps (float += double)
-    float pad1_;
+    float pad0_[2];
 
     RtLightDev lights[RT_DEV_MAX_LIGHTS];
-
-    // object texture (sprite planes) and sky
-    const float *tex_r, *tex_g, *tex_b;
-    int tex_w, tex_h;
-    const float *sky_r, *sky_g, *sky_b;
-    int sky_w, sky_h;
-    float sky_cx, sky_cy, sky_cz, sky_r2;   // skybox sphere centre, radius*radius
-    // the ray-independent part of its quadratic (kernel.cu:293-310 with Org = the frame's ray origin),
-    // formed on the host with the same binary32 operations: oc = Org - centre, C = |oc|^2 - radius^2
-    float sky_ocx, sky_ocy, sky_ocz, sky_C;
-
-    // cubes and planes (SURVEY.md 8(f) row 2): few, tested exhaustively
-    const RtPlaneDev *planes;
-    const RtCubeDev *cubes;
-    int n_planes, n_cubes;
-
-    // triangle mesh behind a flat list of leaf boxes (SURVEY.md 8(f) row 4)
-    const RtTriDev *tris;
-    const RtBoxDev *boxes;
-    const int *tri_idx;
-    const float *box_spheres;   // float4 per leaf: bounding sphere {cx,cy,cz,r^2} for beam culling (+ blocks of leaves)
-    const float *tri9;          // the three vertices (9 floats) of every (leaf, triangle) pair in the order of
-                                // tri_idx: a leaf's triangles are contiguous, one coalesced load stages 7 of them
-    int n_boxes, mesh_has_normals;
-
-    // the sphere table once more in Morton order of the centres, cut into blocks of 64
-    // with a bounding sphere each: culling first tests the blocks, then only the spheres
-    // of the blocks a beam can touch. orig_idx[i] is the list position of sorted[i]
-    // (primary hits must be examined in list order: first index wins ties).
-    const float *sorted;       // float4 per sphere, n_pad entries
-    const float *blocks;       // float4 per block: centre and radius (already padded for its members)
-    const int *orig_idx;
-    int n_blocks, pad_blocks_;
 
     // per light, the table once more: ordered by 2-D Morton code of the centres' coordinates
     // ACROSS the light's axis u = l.pos/|l.pos| and cut into blocks of RT_BLOCK, i.e. columns
@@ -135,16 +88,81 @@ struct RtFrameConsts {
     const float *lsorted[RT_DEV_MAX_LIGHTS];
     const float *lblocks[RT_DEV_MAX_LIGHTS];
 
+    // sky texture and skybox sphere (kernel.cu:1116-1166)
+    const float *sky_r, *sky_g, *sky_b;
+    int sky_w, sky_h;
+    float sky_cx, sky_cy, sky_cz, sky_r2;   // centre, radius*radius
+    float sky_mu_x, sky_mu_y;               // certainty margins of the fast texel-index path, in texels
+
+    // cubes and planes (SURVEY.md 8(f) row 2): few, tested exhaustively
+    const RtPlaneDev *planes;
+    const RtCubeDev *cubes;
+
+    // triangle mesh behind a flat list of leaf boxes (SURVEY.md 8(f) row 4)
+    const RtTriDev *tris;
+    const RtBoxDev *boxes;
+    const int *tri_idx;
+    const float *box_spheres;   // float4 per leaf: bounding sphere {cx,cy,cz,r^2} for beam culling (+ blocks of leaves)
+    const float *tri9;          // the three vertices (9 floats) of every (leaf, triangle) pair in the order of
+                                // tri_idx: a leaf's triangles are contiguous, one coalesced load stages 7 of them
+};
+
+enum {                          // RtFrameConsts::flags
+    RT_FLAG_ACCUMULATE = 1,
+    RT_FLAG_RESOLVE = 2,
+    RT_FLAG_FORCE_SLOW = 4,
+    RT_FLAG_MESH_NORMALS = 8,
+};
+
+// Frame uniforms used all over the kernel, by value (kernel argument -> SGPRs).
+struct RtFrameConsts {
+    // frame / band geometry
+    int width, height;          // full frame (ray generation uses these)
+    int y0, y1;                 // rows rendered by this launch
+    int n_spheres, n_lights;
+    int spp, sample_base;       // samples taken by this launch, index of the first
+    float sample_total;         // divisor at resolve time, as float
+    int flags;                  // RT_FLAG_*
+    int il_count, il_index, il_rows;   // interleaved row blocks (multi-GPU); il_count <= 1: contiguous band
+    int local_rows;             // rows rendered by this launch (= y1 - y0 for a contiguous band)
+    int n_planes, n_cubes, n_boxes;
+    int ablate;                 // RT_TUNING builds only (RT_ABLATE): skip parts of the kernel to price them; 0 otherwise
+
+    // primary rays (kernel.cu:1624-1631, 248-258). dx and dy of kernel.cu:1624-1625 depend on
+    // the column (resp. row) and the sample only: the host evaluates the reference's binary64
+    // expressions once per column and row (rt_scene raygen tables) instead of every pixel
+    // dividing in binary64 twice. dx_tab[s * width + px], dy_tab[s * height + py].
+    const float *dx_tab, *dy_tab;
+    float eye_nz;               // -( -1/aspect ) : z component of (dir - eyePos)
+    float org_x, org_y, org_z;  // eyePos + cam.Org
+    float cos_pitch, sin_pitch, cos_yaw, sin_yaw;
+
+    // object texture (sprite planes)
+    const float *tex_r, *tex_g, *tex_b;
+    int tex_w, tex_h;
+    float tex_mu_x, tex_mu_y;   // certainty margins of the fast texel-index path, in texels
+
+    // the sphere table once more in Morton order of the centres, cut into blocks of RT_BLOCK
+    // with a bounding sphere each: culling first tests the blocks, then only the spheres
+    // of the blocks a beam can touch. orig_idx[i] is the list position of sorted[i]
+    // (primary hits must be examined in list order: first index wins ties).
+    const float *sorted;       // float4 per sphere, n_pad entries
+    const float *blocks;       // float4 per block: centre and radius (already padded for its members)
+    const int *orig_idx;
+    int n_blocks;
+
     // for the primary rays, the table ordered by the DIRECTION of the centres as seen from the
     // ray origin and cut into blocks of RT_BLOCK, i.e. cones from the eye. Two float4 per
     // block: {unit axis, cos(theta)} and {sin(theta), flag, -, -}: theta bounds, for every
     // member, the angle between the axis and any ray from the origin that can pass the
     // member test of a beam with slope <= cone_kcap (flag 1: unbounded, always examined;
     // -1: padding). corig: list position of every entry. Null: use `sorted`/`blocks`.
+    float cone_kcap;
     const float *csorted;
     const float *cblocks;
     const int *corig;
-    float cone_kcap, pad_cone_;
+
+    const RtFrameAux *aux;      // device memory, see above
 
     // outputs
     float *rgba;                // float4 per pixel, band-local, may be null

@@ -24,10 +24,10 @@
 #include "rt_device.h"
 #include "rt_internal.h"
 #include "rt_math.h"
+#include "rt_tables.h"
 
 // launchers defined in rt_kernels.hip
-extern "C" hipError_t rt_dev_launch_trace(const RtFrameConsts *fc, const float4 *spheres, int tile_w,
-                                          int cull, int stats, int table_in_lds, hipStream_t stream);
+extern "C" hipError_t rt_dev_launch_dbg_shortcuts(int what, unsigned seed, long long n, unsigned long long *out, hipStream_t stream);
 extern "C" hipError_t rt_dev_launch_dbg_math(int op, const float *a, const float *b, float *out, int n,
                                              hipStream_t stream);
 extern "C" hipError_t rt_dev_launch_dbg_intersect(const float4 *tab, const float *rays, int n, int *hit,
@@ -96,9 +96,11 @@ extern "C" void *rt_managed_alloc(size_t len)
     checkHipErrors(hipDeviceSynchronize());
     return ptr;
 }
+static void shim_forget(const void *ptr);
 extern "C" void rt_managed_free(void *ptr)
 {
     if (!ptr) return;
+    shim_forget(ptr);   // a sprite / mesh re-created at the same address must be uploaded again
     checkHipErrors(hipDeviceSynchronize());
     (void)hipFree(ptr);
 }
@@ -106,6 +108,31 @@ extern "C" void rt_managed_free(void *ptr)
 // ---------------------------------------------------------------------------
 // device-resident scene
 // ---------------------------------------------------------------------------
+// Frames in flight and the buffers they read. A frame is asynchronous work on the caller's
+// stream; the scene's device buffers may be read by frames on several streams at once (two
+// frames in flight, a replaying graph). Whoever is about to overwrite or free such a buffer
+// first waits for the frames launched so far -- not for the whole device:
+//   * every launch records an event into a ring of RT_RING slots; before a slot is re-used the
+//     launching stream waits on the event it held, so "the ring's events are done" implies
+//     "every earlier frame is done";
+//   * rare mutations (sphere list, lights, textures, resolution) wait on the host for the ring
+//     (rt_scene_quiesce) and then change the buffers in place;
+//   * the one per-frame mutation, the eye-cone table of a moving camera, never waits on the
+//     host: it rotates through RT_CONE_SLOTS device buffers, the build kernel is ordered after
+//     the slot's last reader with hipStreamWaitEvent, and runs on the frame's own stream.
+#define RT_RING 4
+#define RT_CONE_SLOTS 3
+
+struct ConeSlot {
+    float4 *buf = nullptr;
+    size_t cap = 0;                       // float4 units
+    float org[3] = {0, 0, 0};
+    unsigned long long gen = ~0ull;       // sphere_gen the table was built from
+    bool valid = false;
+    bool used = false;                    // read by some frame since it was built
+    unsigned long long last_use = 0;      // ring sequence number of the last frame that read it
+};
+
 struct rt_scene {
     float4 *d_spheres = nullptr;     // [n] list order | [n_pad] Morton order | [n_blocks] block bounds | [n_pad] ints
     int n_spheres = 0, cap_spheres = 0;
@@ -133,7 +160,7 @@ struct rt_scene {
     float *d_box_spheres = nullptr;
     float *d_tri9 = nullptr;
     int n_boxes = 0, n_tris = 0, mesh_has_normals = 0;
-    // per-light column blocks (see RtFrameConsts::lsorted): one allocation, rebuilt when the
+    // per-light column blocks (see RtFrameAux::lsorted): one allocation, rebuilt when the
     // sphere list or a light's position changes
     float4 *d_light_tabs = nullptr;
     size_t cap_light_tabs = 0;           // float4 units
@@ -142,30 +169,45 @@ struct rt_scene {
     int ltab_n_lights = 0;
     float ltab_axis[RT_MAX_LIGHTS][3];   // axis each table was built for
     bool ltab_valid[RT_MAX_LIGHTS] = {};
-    // eye cones for the primary rays (see RtFrameConsts::csorted): rebuilt when the sphere
-    // list or the ray origin changes
-    float4 *d_cone_tab = nullptr;
-    size_t cap_cone_tab = 0;             // float4 units
-    unsigned long long cone_gen = ~0ull;
-    float cone_org[3] = {0, 0, 0};
-    bool cone_valid = false;
+    // eye cones for the primary rays (see RtFrameConsts::csorted), one table per recent ray origin
+    ConeSlot cones[RT_CONE_SLOTS];
+    // dx / dy of the primary rays per column / row and sample (RtFrameConsts::dx_tab)
+    float *d_raygen = nullptr;
+    size_t cap_raygen = 0;               // floats
+    int rg_w = 0, rg_h = 0, rg_total = 0;
+    float rg_aspect = 0.f;
+    // RtFrameAux as uploaded last
+    RtFrameAux h_aux;
+    RtFrameAux *d_aux = nullptr;
+    bool aux_valid = false;
+    // frames in flight
+    hipEvent_t ring[RT_RING] = {};
+    bool ring_used[RT_RING] = {};
+    unsigned long long ring_seq = 0;     // sequence number of the next launch
+    // bumped whenever a buffer a recorded graph may point into is rewritten or re-allocated
+    unsigned long long epoch = 0;
+#ifdef RT_TUNING
+    int tune_no_eye_cones = 0, tune_no_light_columns = 0, tune_table_lds = 0, tune_ablate = 0;
+#endif
 };
 
-// Where the kernel reads the sphere table from. Default: global memory (L2-resident), LDS
-// holding only each wave's survivor lists -- the tile's spheres, broadcast across lanes.
-// RT_TABLE_LDS=1 stages the whole table in LDS per workgroup of RT_WAVES_PER_WG waves when
-// it fits (the round's first design; measured slower: 0.71 vs 0.68 ms at 1024 spheres,
-// 4.5 vs 2.6 ms at 4096), RT_TABLE_LDS=0 forces the default.
 static const int kMaxSpheresLds = (160 * 1024 - RT_WAVES_PER_WG * (RT_LIST_CAP * 20 + 16 * 4 + 64 * 4 + RT_BOX_CAP * 4)) / 16;
 static const int kMaxSpheres = 1 << 22;
-static int table_in_lds_for(int n)
-{
-    const char *e = getenv("RT_TABLE_LDS");   // tuning/testing override
-    if (e && *e == '1') return n <= kMaxSpheresLds ? 1 : 0;
-    return 0;
-}
 
-extern "C" rt_scene *rt_scene_create(void) { return new rt_scene(); }
+extern "C" rt_scene *rt_scene_create(void)
+{
+    rt_scene *s = new rt_scene();
+    memset(&s->h_aux, 0, sizeof s->h_aux);
+#ifdef RT_TUNING
+    // tuning builds (make EXTRA=-DRT_TUNING, tools/variants.sh) read their switches once per scene;
+    // the product library reads no environment
+    if (const char *e = getenv("RT_NO_EYE_CONES")) s->tune_no_eye_cones = atoi(e);
+    if (const char *e = getenv("RT_NO_LIGHT_COLUMNS")) s->tune_no_light_columns = atoi(e);
+    if (const char *e = getenv("RT_TABLE_LDS")) s->tune_table_lds = atoi(e);
+    if (const char *e = getenv("RT_ABLATE")) s->tune_ablate = atoi(e);
+#endif
+    return s;
+}
 
 static void free_planes(float *p[3])
 {
@@ -175,9 +217,44 @@ static void free_planes(float *p[3])
     }
 }
 
+// Wait (on the host) for every frame launched on this scene so far.
+int rt_scene_quiesce(rt_scene *s)
+{
+    for (int i = 0; i < RT_RING; ++i)
+        if (s->ring_used[i]) RT_HIP(hipEventSynchronize(s->ring[i]));
+    return RT_OK;
+}
+
+// Make `stream` wait for every frame launched on this scene so far (no host wait).
+static int stream_wait_all_frames(rt_scene *s, hipStream_t stream)
+{
+    for (int i = 0; i < RT_RING; ++i)
+        if (s->ring_used[i]) RT_HIP(hipStreamWaitEvent(stream, s->ring[i], 0));
+    return RT_OK;
+}
+
+// A frame has just been enqueued on `stream`: give it the next ring slot. `cone_slot` >= 0:
+// the eye-cone table the frame reads.
+int rt_scene_note_launch(rt_scene *s, hipStream_t stream, int cone_slot)
+{
+    const int k = (int)(s->ring_seq % RT_RING);
+    if (!s->ring[k]) RT_HIP(hipEventCreateWithFlags(&s->ring[k], hipEventDisableTiming));
+    // chain: whoever sees this slot's new event done has also seen the one it replaces
+    if (s->ring_used[k]) RT_HIP(hipStreamWaitEvent(stream, s->ring[k], 0));
+    RT_HIP(hipEventRecord(s->ring[k], stream));
+    s->ring_used[k] = true;
+    if (cone_slot >= 0) {
+        s->cones[cone_slot].used = true;
+        s->cones[cone_slot].last_use = s->ring_seq;
+    }
+    s->ring_seq++;
+    return RT_OK;
+}
+
 extern "C" void rt_scene_destroy(rt_scene *s)
 {
     if (!s) return;
+    (void)rt_scene_quiesce(s);
     if (s->d_spheres) (void)hipFree(s->d_spheres);
     if (s->h_stage) (void)hipHostFree(s->h_stage);
     if (s->stage_done) (void)hipEventDestroy(s->stage_done);
@@ -191,7 +268,12 @@ extern "C" void rt_scene_destroy(rt_scene *s)
     if (s->d_box_spheres) (void)hipFree(s->d_box_spheres);
     if (s->d_tri9) (void)hipFree(s->d_tri9);
     if (s->d_light_tabs) (void)hipFree(s->d_light_tabs);
-    if (s->d_cone_tab) (void)hipFree(s->d_cone_tab);
+    for (ConeSlot &c : s->cones)
+        if (c.buf) (void)hipFree(c.buf);
+    if (s->d_raygen) (void)hipFree(s->d_raygen);
+    if (s->d_aux) (void)hipFree(s->d_aux);
+    for (hipEvent_t e : s->ring)
+        if (e) (void)hipEventDestroy(e);
     delete s;
 }
 
@@ -203,310 +285,101 @@ static void pack_spheres(const rt_sphere *src, int n, float4 *dst)
         dst[i] = make_float4(src[i].orgin.x, src[i].orgin.y, src[i].orgin.z, src[i].radius * src[i].radius);
 }
 
-// Morton order of the centres (10 bits per axis over the scene's bounds), blocks of
-// RT_BLOCK consecutive spheres, and for each block a sphere that contains every member
-// (centre = mean of the members' centres, radius = max |c_i - centre| + R_i, rounded
-// up). Spheres with non-finite data make their block unbounded (always examined).
-static unsigned morton10(unsigned v)
-{
-    v &= 0x3ffu;
-    v = (v | (v << 16)) & 0x030000ffu;
-    v = (v | (v << 8)) & 0x0300f00fu;
-    v = (v | (v << 4)) & 0x030c30c3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
-}
-
-static void build_sorted_blocks(const float4 *tab, int n, float4 *sorted, float4 *blocks, int *orig)
-{
-    const int n_pad = (n + 63) & ~63;
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = 0; i < n; ++i) {
-        const float c[3] = {tab[i].x, tab[i].y, tab[i].z};
-        for (int k = 0; k < 3; ++k)
-            if (std::isfinite(c[k])) {
-                lo[k] = std::min(lo[k], c[k]);
-                hi[k] = std::max(hi[k], c[k]);
-            }
-    }
-    std::vector<std::pair<unsigned, int>> keys((size_t)n);
-    for (int i = 0; i < n; ++i) {
-        const float c[3] = {tab[i].x, tab[i].y, tab[i].z};
-        unsigned q[3];
-        for (int k = 0; k < 3; ++k) {
-            const float span = hi[k] - lo[k];
-            const float t = (std::isfinite(c[k]) && span > 0) ? (c[k] - lo[k]) / span : 0.f;
-            q[k] = (unsigned)std::min(1023.f, std::max(0.f, t * 1023.f));
-        }
-        keys[i] = {morton10(q[0]) | (morton10(q[1]) << 1) | (morton10(q[2]) << 2), i};
-    }
-    std::sort(keys.begin(), keys.end());
-    for (int i = 0; i < n_pad; ++i) {
-        sorted[i] = i < n ? tab[keys[i].second] : make_float4(0.f, 0.f, 0.f, 0.f);
-        orig[i] = i < n ? keys[i].second : 0x7fffffff;
-    }
-    for (int b = 0; b < n_pad / RT_BLOCK; ++b) {
-        const int i0 = b * RT_BLOCK, i1 = std::min(n, i0 + RT_BLOCK);
-        if (i0 >= n) {   // padding block: nothing in it, never examined
-            blocks[b] = make_float4(0.f, 0.f, 0.f, -1.f);
-            continue;
-        }
-        double cx = 0, cy = 0, cz = 0;
-        for (int i = i0; i < i1; ++i) { cx += sorted[i].x; cy += sorted[i].y; cz += sorted[i].z; }
-        const double inv = 1.0 / std::max(1, i1 - i0);
-        cx *= inv; cy *= inv; cz *= inv;
-        double r = 0;
-        for (int i = i0; i < i1; ++i) {
-            const double dx = sorted[i].x - cx, dy = sorted[i].y - cy, dz = sorted[i].z - cz;
-            const double ri = std::sqrt(std::max(0.0, (double)sorted[i].w));
-            const double d = std::sqrt(dx * dx + dy * dy + dz * dz) + ri;
-            r = (d > r || d != d) ? d : r;   // a NaN sticks
-        }
-        float rf = (float)(r * 1.001 + 1e-3);
-        if (!(rf == rf) || !std::isfinite(cx + cy + cz)) { rf = INFINITY; cx = cy = cz = 0; }
-        blocks[b] = make_float4((float)cx, (float)cy, (float)cz, rf);
-    }
-}
-
 // ---------------------------------------------------------------------------
-// Per-light column blocks. All shadow rays of a light run within a few degrees of
-// u = l.pos/|l.pos| (kernel.cu:1468 builds them relative to the world origin), so the table
-// is ordered by where the centres fall ACROSS u and cut into blocks of RT_BLOCK: columns
-// along u, which a beam along u touches far less often than the cubes of the 3-D order.
-// Block record, two float4: {cx, cy, cz, rho} and {s_hi, r3d, 0, 0} -- c the mean centre,
-// rho >= |(c_j - c) across u| + R_j, s_hi >= (c_j - c).u + R_j, r3d >= |c_j - c| + R_j for
-// every member j (R_j = sqrt of the table's squared effective radius), all rounded up.
+// eye cones: which table a frame with ray origin `org` reads, building it if need be
 // ---------------------------------------------------------------------------
-static unsigned morton16(unsigned v)
+static bool eye_cones_wanted(const rt_scene *s, const float org[3])
 {
-    v &= 0xffffu;
-    v = (v | (v << 8)) & 0x00ff00ffu;
-    v = (v | (v << 4)) & 0x0f0f0f0fu;
-    v = (v | (v << 2)) & 0x33333333u;
-    v = (v | (v << 1)) & 0x55555555u;
-    return v;
+#ifdef RT_TUNING
+    if (s->tune_no_eye_cones) return false;
+#endif
+    return s->n_spheres >= 64 && s->h_prev.size() == (size_t)s->n_spheres && std::isfinite(org[0]) &&
+           std::isfinite(org[1]) && std::isfinite(org[2]);
 }
 
-static void build_light_columns(const float4 *tab, int n, const float u_f[3], float4 *sorted, float4 *blocks)
-{
-    const int n_pad = (n + 63) & ~63;
-    const double u[3] = {u_f[0], u_f[1], u_f[2]};
-    // two directions across u
-    double e1[3] = {0, 0, 0};
-    {
-        const int k = (std::fabs(u[0]) <= std::fabs(u[1]) && std::fabs(u[0]) <= std::fabs(u[2])) ? 0
-                      : (std::fabs(u[1]) <= std::fabs(u[2]) ? 1 : 2);
-        double t[3] = {0, 0, 0};
-        t[k] = 1;
-        const double d = t[0] * u[0] + t[1] * u[1] + t[2] * u[2];
-        for (int i = 0; i < 3; ++i) e1[i] = t[i] - d * u[i];
-        const double l = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
-        for (int i = 0; i < 3; ++i) e1[i] /= l;
-    }
-    const double e2[3] = {u[1] * e1[2] - u[2] * e1[1], u[2] * e1[0] - u[0] * e1[2], u[0] * e1[1] - u[1] * e1[0]};
-    std::vector<double> p1((size_t)n), p2((size_t)n);
-    double lo1 = INFINITY, hi1 = -INFINITY, lo2 = INFINITY, hi2 = -INFINITY;
-    std::vector<char> fin((size_t)n);
-    for (int i = 0; i < n; ++i) {
-        const double c[3] = {tab[i].x, tab[i].y, tab[i].z};
-        p1[i] = c[0] * e1[0] + c[1] * e1[1] + c[2] * e1[2];
-        p2[i] = c[0] * e2[0] + c[1] * e2[1] + c[2] * e2[2];
-        fin[i] = std::isfinite(p1[i]) && std::isfinite(p2[i]) && std::isfinite((double)tab[i].w);
-        if (fin[i]) {
-            lo1 = std::min(lo1, p1[i]); hi1 = std::max(hi1, p1[i]);
-            lo2 = std::min(lo2, p2[i]); hi2 = std::max(hi2, p2[i]);
-        }
-    }
-    std::vector<std::pair<unsigned long long, int>> keys((size_t)n);
-    for (int i = 0; i < n; ++i) {
-        unsigned long long key = ~0ull;   // non-finite entries go last (their blocks are unbounded)
-        if (fin[i]) {
-            const double s1 = hi1 - lo1, s2 = hi2 - lo2;
-            const unsigned q1 = (unsigned)std::min(65535.0, std::max(0.0, s1 > 0 ? (p1[i] - lo1) / s1 * 65535.0 : 0.0));
-            const unsigned q2 = (unsigned)std::min(65535.0, std::max(0.0, s2 > 0 ? (p2[i] - lo2) / s2 * 65535.0 : 0.0));
-            key = morton16(q1) | ((unsigned long long)morton16(q2) << 1);
-        }
-        keys[i] = {key, i};
-    }
-    std::sort(keys.begin(), keys.end());
-    for (int i = 0; i < n_pad; ++i) sorted[i] = i < n ? tab[keys[i].second] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int b = 0; b < n_pad / RT_BLOCK; ++b) {
-        const int i0 = b * RT_BLOCK, i1 = std::min(n, i0 + RT_BLOCK);
-        if (i0 >= n) {   // padding block: nothing in it, never examined
-            blocks[2 * b] = make_float4(0.f, 0.f, 0.f, -1.f);
-            blocks[2 * b + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
-            continue;
-        }
-        double cx = 0, cy = 0, cz = 0;
-        for (int i = i0; i < i1; ++i) { cx += sorted[i].x; cy += sorted[i].y; cz += sorted[i].z; }
-        const double inv = 1.0 / std::max(1, i1 - i0);
-        // the bounds below are taken around the ROUNDED centre the device will use
-        const float cf[3] = {(float)(cx * inv), (float)(cy * inv), (float)(cz * inv)};
-        double rho = 0, s_hi = -INFINITY, r3d = 0;
-        bool bad = !(std::isfinite(cf[0]) && std::isfinite(cf[1]) && std::isfinite(cf[2]));
-        for (int i = i0; i < i1 && !bad; ++i) {
-            const double d[3] = {sorted[i].x - (double)cf[0], sorted[i].y - (double)cf[1], sorted[i].z - (double)cf[2]};
-            const double w = sorted[i].w;
-            if (!(w == w) || !std::isfinite(d[0] + d[1] + d[2]) || !std::isfinite(w)) { bad = true; break; }
-            const double R = std::sqrt(std::max(0.0, w));
-            const double ax = d[0] * u[0] + d[1] * u[1] + d[2] * u[2];
-            const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-            const double lat = std::sqrt(std::max(0.0, dd - ax * ax));
-            rho = std::max(rho, lat + R);
-            s_hi = std::max(s_hi, ax + R);
-            r3d = std::max(r3d, std::sqrt(dd) + R);
-        }
-        if (bad) {   // always examined
-            blocks[2 * b] = make_float4(0.f, 0.f, 0.f, INFINITY);
-            blocks[2 * b + 1] = make_float4(INFINITY, INFINITY, 0.f, 0.f);
-            continue;
-        }
-        // rounded up; |u| differs from 1 by a few 1e-8, which the factors cover as well
-        blocks[2 * b] = make_float4(cf[0], cf[1], cf[2], (float)(rho * 1.001 + 1e-3));
-        blocks[2 * b + 1] = make_float4((float)(s_hi + std::fabs(s_hi) * 1e-3 + 1e-3), (float)(r3d * 1.001 + 1e-3), 0.f, 0.f);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Eye cones. Every primary ray starts at the same point O, so the table is ordered by the
-// direction of the centres as seen from O (octahedral map, 2-D Morton) and cut into blocks of
-// RT_BLOCK: cones from O that a tile's thin beam meets far less often than the cubes of the
-// 3-D order. For a beam with apex O, r0 = 1e-4, smin = 0 and slope k <= kcap the member test
-// of the kernel (beam_member_test) passes only if the angle alpha between the beam axis and
-// the direction to the centre satisfies sin(alpha - atan(1.00025 k)) <= (rc (1 + k) + r0) 1.00025 / |v|,
-// rc = sqrt(R^2 + 4e-5 |v|^2 + 1e-3) 1.0001 -- all known here because the apex is. theta of
-// a block: max over members of (angle(axis, dir_j) + asin of that bound), plus margin.
-// ---------------------------------------------------------------------------
-static const float kConeKcap = 0.1f;
-
-static void oct_map(const double d[3], double *u, double *v)
-{
-    const double s = std::fabs(d[0]) + std::fabs(d[1]) + std::fabs(d[2]);
-    double x = d[0] / s, y = d[1] / s;
-    if (d[2] < 0) {
-        const double ox = (1 - std::fabs(y)) * (x >= 0 ? 1 : -1), oy = (1 - std::fabs(x)) * (y >= 0 ? 1 : -1);
-        x = ox; y = oy;
-    }
-    *u = x; *v = y;
-}
-
-static void build_eye_cones(const float4 *tab, int n, const float org[3], float4 *sorted, float4 *blocks, int *orig)
-{
-    const int n_pad = (n + 63) & ~63;
-    const double kcap = kConeKcap, r0 = 1.0e-4;
-    struct Ent { double dir[3]; double ext; bool bounded; };
-    std::vector<Ent> ent((size_t)n);
-    std::vector<std::pair<unsigned long long, int>> keys((size_t)n);
-    for (int i = 0; i < n; ++i) {
-        Ent &e = ent[i];
-        const double v[3] = {(double)tab[i].x - org[0], (double)tab[i].y - org[1], (double)tab[i].z - org[2]};
-        const double vv = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], dist = std::sqrt(vv), w = tab[i].w;
-        e.bounded = std::isfinite(vv) && std::isfinite(w) && dist > 0;
-        e.ext = 0;
-        if (e.bounded) {
-            const double rc = std::sqrt(std::max(0.0, w) + 4.0e-5 * vv + 1.0e-3) * 1.0001;
-            const double q = (rc * (1.0 + kcap) + r0) * 1.00025 * 1.001 / dist;
-            if (!(q < 0.99)) e.bounded = false;   // the origin is inside or next to the (padded) sphere
-            else e.ext = std::asin(q);
-            for (int k = 0; k < 3; ++k) e.dir[k] = v[k] / dist;
-        }
-        unsigned long long key = ~0ull;   // unbounded entries go last
-        if (e.bounded) {
-            double ou, ov;
-            oct_map(e.dir, &ou, &ov);
-            const unsigned q1 = (unsigned)std::min(65535.0, std::max(0.0, (ou * 0.5 + 0.5) * 65535.0));
-            const unsigned q2 = (unsigned)std::min(65535.0, std::max(0.0, (ov * 0.5 + 0.5) * 65535.0));
-            key = morton16(q1) | ((unsigned long long)morton16(q2) << 1);
-        }
-        keys[i] = {key, i};
-    }
-    std::sort(keys.begin(), keys.end());
-    for (int i = 0; i < n_pad; ++i) {
-        sorted[i] = i < n ? tab[keys[i].second] : make_float4(0.f, 0.f, 0.f, 0.f);
-        orig[i] = i < n ? keys[i].second : 0x7fffffff;
-    }
-    for (int b = 0; b < n_pad / RT_BLOCK; ++b) {
-        const int i0 = b * RT_BLOCK, i1 = std::min(n, i0 + RT_BLOCK);
-        if (i0 >= n) {   // padding block: nothing in it, never examined
-            blocks[2 * b] = make_float4(0.f, 0.f, 0.f, 0.f);
-            blocks[2 * b + 1] = make_float4(0.f, -1.f, 0.f, 0.f);
-            continue;
-        }
-        bool bounded = true;
-        double m[3] = {0, 0, 0};
-        for (int i = i0; i < i1; ++i) {
-            const Ent &e = ent[keys[i].second];
-            bounded = bounded && e.bounded;
-            if (e.bounded) for (int k = 0; k < 3; ++k) m[k] += e.dir[k];
-        }
-        const double ml = std::sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
-        bounded = bounded && ml > 1e-6;
-        float af[3] = {0, 0, 0};
-        double theta = 0;
-        if (bounded) {
-            for (int k = 0; k < 3; ++k) af[k] = (float)(m[k] / ml);
-            // angles are taken from the ROUNDED axis the device will use
-            const double al = std::sqrt((double)af[0] * af[0] + (double)af[1] * af[1] + (double)af[2] * af[2]);
-            for (int i = i0; i < i1; ++i) {
-                const Ent &e = ent[keys[i].second];
-                double c = (af[0] * e.dir[0] + af[1] * e.dir[1] + af[2] * e.dir[2]) / al;
-                c = std::min(1.0, std::max(-1.0, c));
-                theta = std::max(theta, std::acos(c) + e.ext);
-            }
-            theta += 2.0e-3;
-            if (!(theta < 2.9)) bounded = false;   // theta + the beam's own angle must stay below pi
-        }
-        if (!bounded) {
-            blocks[2 * b] = make_float4(0.f, 0.f, 0.f, 0.f);
-            blocks[2 * b + 1] = make_float4(0.f, 1.f, 0.f, 0.f);
-            continue;
-        }
-        blocks[2 * b] = make_float4(af[0], af[1], af[2], (float)std::cos(theta));
-        blocks[2 * b + 1] = make_float4((float)std::sin(theta), 0.f, 0.f, 0.f);
-    }
-}
-
-// Bring the eye cones up to date with the mirrored sphere list and the ray origin `org`
-// (= RtFrameConsts::org_*). Not inside a stream capture.
-int rt_scene_prepare_eye(rt_scene *s, const float org[3], hipStream_t stream)
+// Fill `buf` (rt_eye_cones_size(n) float4) for `org`: on the device, on `stream`, when the list
+// fits the one-workgroup builder; else on the host with a blocking upload (the caller has made
+// sure nothing reads `buf`).
+static int build_eye_cones_into(rt_scene *s, const float org[3], float4 *buf, hipStream_t stream)
 {
     const int n = s->n_spheres;
-    const int n_pad = (n + 63) & ~63, nb = n_pad / RT_BLOCK;
-    const bool want = n >= 64 && s->h_prev.size() == (size_t)n && !getenv("RT_NO_EYE_CONES") &&
-                      std::isfinite(org[0]) && std::isfinite(org[1]) && std::isfinite(org[2]);
-    if (!want) {
-        s->cone_valid = false;
-        s->cone_gen = ~0ull;
+    if (((n + 63) & ~63) <= RT_EYE_DEVICE_MAX) {
+        RT_HIP(rt_eye_cones_launch(s->d_spheres, n, org, buf, stream));
         return RT_OK;
     }
-    if (s->cone_valid && s->cone_gen == s->sphere_gen && memcmp(org, s->cone_org, sizeof s->cone_org) == 0) return RT_OK;
-    const size_t total = (size_t)n_pad + 2 * (size_t)nb + ((size_t)n_pad + 3) / 4;   // float4 units
-    if (total > s->cap_cone_tab) {
-        if (s->d_cone_tab) RT_HIP(hipFree(s->d_cone_tab));
-        s->d_cone_tab = nullptr;
-        s->cap_cone_tab = 0;
-        RT_HIP(hipMalloc((void **)&s->d_cone_tab, sizeof(float4) * total));
-        s->cap_cone_tab = total;
-    }
-    // frames still in flight (another stream, a replaying graph) may be reading the old table
-    RT_HIP(hipDeviceSynchronize());
-    std::vector<float4> h(total);
-    build_eye_cones(s->h_prev.data(), n, org, h.data(), h.data() + n_pad, reinterpret_cast<int *>(h.data() + n_pad + 2 * nb));
-    RT_HIP(hipMemcpyAsync(s->d_cone_tab, h.data(), sizeof(float4) * total, hipMemcpyHostToDevice, stream));
-    RT_HIP(hipStreamSynchronize(stream));   // `h` goes out of scope; only when the eye or the scene moved
-    s->cone_gen = s->sphere_gen;
-    memcpy(s->cone_org, org, sizeof s->cone_org);
-    s->cone_valid = true;
+    const int n_pad = (n + 63) & ~63, nb = n_pad / RT_BLOCK;
+    std::vector<float4> h(rt_eye_cones_size(n));
+    rt_build_eye_cones_host(s->h_prev.data(), n, org, h.data(), h.data() + n_pad, reinterpret_cast<int *>(h.data() + n_pad + 2 * nb));
+    RT_HIP(hipMemcpyAsync(buf, h.data(), sizeof(float4) * h.size(), hipMemcpyHostToDevice, stream));
+    RT_HIP(hipStreamSynchronize(stream));   // `h` goes out of scope
     return RT_OK;
 }
 
-// Bring the per-light tables up to date with the mirrored sphere list and the lights'
-// positions. Not inside a stream capture (rt_graph_capture calls it first).
-int rt_scene_prepare_lights(rt_scene *s, hipStream_t stream)
+// Returns the slot whose table is current for `org` (building it on `stream` if none is), or
+// -1 when the scene renders without eye cones. Not inside a stream capture.
+static int rt_scene_prepare_eye(rt_scene *s, const float org[3], hipStream_t stream, int *slot_out)
+{
+    *slot_out = -1;
+    if (!eye_cones_wanted(s, org)) return RT_OK;
+    for (int i = 0; i < RT_CONE_SLOTS; ++i) {
+        const ConeSlot &c = s->cones[i];
+        if (c.valid && c.gen == s->sphere_gen && memcmp(org, c.org, sizeof c.org) == 0) {
+            *slot_out = i;
+            return RT_OK;
+        }
+    }
+    // victim: an unused or stale slot, else the one read longest ago
+    int v = 0;
+    for (int i = 0; i < RT_CONE_SLOTS; ++i) {
+        const ConeSlot &c = s->cones[i], &b = s->cones[v];
+        const bool c_free = !c.valid || c.gen != s->sphere_gen, b_free = !b.valid || b.gen != s->sphere_gen;
+        if ((c_free && !b_free) || (c_free == b_free && (!c.used || (b.used && c.last_use < b.last_use)))) v = i;
+    }
+    ConeSlot &c = s->cones[v];
+    const size_t total = rt_eye_cones_size(s->n_spheres);
+    const bool host_build = ((s->n_spheres + 63) & ~63) > RT_EYE_DEVICE_MAX;
+    if (total > c.cap || host_build) {
+        const int rc = rt_scene_quiesce(s);   // nothing may still read the buffer that is freed / overwritten from the host
+        if (rc != RT_OK) return rc;
+    }
+    if (total > c.cap) {
+        if (c.buf) RT_HIP(hipFree(c.buf));
+        c.buf = nullptr;
+        c.cap = 0;
+        c.valid = false;
+        RT_HIP(hipMalloc((void **)&c.buf, sizeof(float4) * total));
+        c.cap = total;
+        s->epoch++;
+    } else if (c.used && !host_build) {
+        // order the rebuild after the last frame that read this slot -- on the device only
+        if (s->ring_seq - c.last_use <= RT_RING) RT_HIP(hipStreamWaitEvent(stream, s->ring[c.last_use % RT_RING], 0));
+        else {
+            const int rc = stream_wait_all_frames(s, stream);
+            if (rc != RT_OK) return rc;
+        }
+    }
+    c.valid = false;
+    const int rc = build_eye_cones_into(s, org, c.buf, stream);
+    if (rc != RT_OK) return rc;
+    memcpy(c.org, org, sizeof c.org);
+    c.gen = s->sphere_gen;
+    c.valid = true;
+    c.used = false;
+    *slot_out = v;
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// per-light column tables (host build: lights and the list rarely change)
+// ---------------------------------------------------------------------------
+static int rt_scene_prepare_lights(rt_scene *s, hipStream_t stream)
 {
     const int n = s->n_spheres;
     const int n_pad = (n + 63) & ~63, nb = n_pad / RT_BLOCK;
-    const bool want = n >= 64 && s->h_prev.size() == (size_t)n && !getenv("RT_NO_LIGHT_COLUMNS");
+    bool want = n >= 64 && s->h_prev.size() == (size_t)n;
+#ifdef RT_TUNING
+    if (s->tune_no_light_columns) want = false;
+#endif
     if (!want) {
         for (int i = 0; i < RT_MAX_LIGHTS; ++i) s->ltab_valid[i] = false;
         s->ltab_gen = ~0ull;
@@ -528,6 +401,9 @@ int rt_scene_prepare_lights(rt_scene *s, hipStream_t stream)
                (!usable[i] || memcmp(axis[i], s->ltab_axis[i], sizeof axis[i]) == 0);
     }
     if (same) return RT_OK;
+    // frames still in flight (another stream, a replaying graph) may be reading the old tables
+    int rc = rt_scene_quiesce(s);
+    if (rc != RT_OK) return rc;
     const size_t total = per_light * (size_t)std::max(1, s->n_lights);
     if (total > s->cap_light_tabs) {
         if (s->d_light_tabs) RT_HIP(hipFree(s->d_light_tabs));
@@ -536,21 +412,19 @@ int rt_scene_prepare_lights(rt_scene *s, hipStream_t stream)
         RT_HIP(hipMalloc((void **)&s->d_light_tabs, sizeof(float4) * total));
         s->cap_light_tabs = total;
     }
-    // frames still in flight (another stream, a replaying graph) may be reading the old tables
-    RT_HIP(hipDeviceSynchronize());
     std::vector<float4> h(total);
     for (int i = 0; i < s->n_lights; ++i) {
         s->ltab_valid[i] = usable[i];
         memcpy(s->ltab_axis[i], axis[i], sizeof axis[i]);
         if (usable[i])
-            build_light_columns(s->h_prev.data(), n, axis[i], h.data() + per_light * i, h.data() + per_light * i + n_pad);
+            rt_build_light_columns(s->h_prev.data(), n, axis[i], h.data() + per_light * i, h.data() + per_light * i + n_pad);
     }
     for (int i = s->n_lights; i < RT_MAX_LIGHTS; ++i) s->ltab_valid[i] = false;
-    // pageable source: the copy has left `h` when the call returns
     RT_HIP(hipMemcpyAsync(s->d_light_tabs, h.data(), sizeof(float4) * total, hipMemcpyHostToDevice, stream));
     RT_HIP(hipStreamSynchronize(stream));   // rare (scene or light change): `h` goes out of scope
     s->ltab_gen = s->sphere_gen;
     s->ltab_n_lights = s->n_lights;
+    s->epoch++;
     return RT_OK;
 }
 
@@ -566,6 +440,19 @@ int rt_scene_set_spheres_async(rt_scene *s, const rt_sphere *host_spheres, int n
     }
     const int n_pad = (n + 63) & ~63, nb = n_pad / RT_BLOCK;
     const size_t total = (size_t)n + (size_t)n_pad + (size_t)nb + ((size_t)n_pad + 3) / 4;   // in float4 units
+    std::vector<float4> packed((size_t)n);
+    if (n > 0) {
+        pack_spheres(host_spheres, n, packed.data());
+        if (s->n_spheres == n && s->h_prev.size() == (size_t)n && (int)total <= s->cap_spheres &&
+            memcmp(s->h_prev.data(), packed.data(), sizeof(float4) * (size_t)n) == 0)
+            return RT_OK;   // unchanged since the last mirror: the device copy is current
+    }
+    // the table changes: frames in flight on ANY stream may still be reading the device copy
+    // (two frames in flight, a replaying graph), so wait for them before it is overwritten or freed
+    {
+        const int rc = rt_scene_quiesce(s);
+        if (rc != RT_OK) return rc;
+    }
     if ((int)total > s->cap_spheres) {
         if (s->d_spheres) RT_HIP(hipFree(s->d_spheres));
         s->d_spheres = nullptr;
@@ -583,27 +470,22 @@ int rt_scene_set_spheres_async(rt_scene *s, const rt_sphere *host_spheres, int n
         s->cap_stage = (int)total;
     }
     if (n > 0) {
-        std::vector<float4> packed((size_t)n);
-        pack_spheres(host_spheres, n, packed.data());
-        if (s->n_spheres == n && s->h_prev.size() == (size_t)n &&
-            memcmp(s->h_prev.data(), packed.data(), sizeof(float4) * (size_t)n) == 0)
-            return RT_OK;   // unchanged since the last mirror: the device copy is current
-        // the staging buffer is reused every frame: wait for the previous upload to have left it
+        // the staging buffer is reused: wait for the previous upload to have left it
         if (!s->stage_done) RT_HIP(hipEventCreateWithFlags(&s->stage_done, hipEventDisableTiming));
         if (s->stage_busy) RT_HIP(hipEventSynchronize(s->stage_done));
         float4 *h_orig = s->h_stage, *h_sorted = h_orig + n, *h_blocks = h_sorted + n_pad;
         int *h_idx = reinterpret_cast<int *>(h_blocks + nb);
         memcpy(h_orig, packed.data(), sizeof(float4) * (size_t)n);
-        build_sorted_blocks(packed.data(), n, h_sorted, h_blocks, h_idx);
+        rt_build_sorted_blocks(packed.data(), n, h_sorted, h_blocks, h_idx);
         RT_HIP(hipMemcpyAsync(s->d_spheres, s->h_stage, sizeof(float4) * total, hipMemcpyHostToDevice, stream));
         RT_HIP(hipEventRecord(s->stage_done, stream));
         s->stage_busy = true;
         s->h_prev.swap(packed);
-        s->sphere_gen++;
     } else {
         s->h_prev.clear();
-        s->sphere_gen++;
     }
+    s->sphere_gen++;
+    s->epoch++;
     s->n_blocks = nb;
     s->n_spheres = n;
     return RT_OK;
@@ -627,6 +509,7 @@ extern "C" int rt_scene_set_planes(rt_scene *s, const rt_plane *host_planes, int
         rt_set_error("rt_scene_set_planes: %d planes > RT_MAX_PLANES %d", n, RT_MAX_PLANES);
         return RT_ERR_CAPACITY;
     }
+    { const int rc = rt_scene_quiesce(s); if (rc != RT_OK) return rc; }
     if (!s->d_planes) RT_HIP(hipMalloc((void **)&s->d_planes, sizeof(RtPlaneDev) * RT_MAX_PLANES));
     std::vector<RtPlaneDev> tmp(n ? n : 1);
     for (int i = 0; i < n; ++i)
@@ -634,6 +517,7 @@ extern "C" int rt_scene_set_planes(rt_scene *s, const rt_plane *host_planes, int
                             host_planes[i].normal.x, host_planes[i].normal.y, host_planes[i].normal.z, 0.f, 0.f};
     if (n) RT_HIP(hipMemcpy(s->d_planes, tmp.data(), sizeof(RtPlaneDev) * n, hipMemcpyHostToDevice));
     s->n_planes = n;
+    s->epoch++;
     return RT_OK;
 }
 
@@ -647,6 +531,7 @@ extern "C" int rt_scene_set_cubes(rt_scene *s, const rt_cube *host_cubes, int n)
         rt_set_error("rt_scene_set_cubes: %d cubes > RT_MAX_CUBES %d", n, RT_MAX_CUBES);
         return RT_ERR_CAPACITY;
     }
+    { const int rc = rt_scene_quiesce(s); if (rc != RT_OK) return rc; }
     if (!s->d_cubes) RT_HIP(hipMalloc((void **)&s->d_cubes, sizeof(RtCubeDev) * RT_MAX_CUBES));
     std::vector<RtCubeDev> tmp(n ? n : 1);
     for (int i = 0; i < n; ++i) {
@@ -656,6 +541,7 @@ extern "C" int rt_scene_set_cubes(rt_scene *s, const rt_cube *host_cubes, int n)
     }
     if (n) RT_HIP(hipMemcpy(s->d_cubes, tmp.data(), sizeof(RtCubeDev) * n, hipMemcpyHostToDevice));
     s->n_cubes = n;
+    s->epoch++;
     return RT_OK;
 }
 
@@ -667,6 +553,8 @@ extern "C" int rt_scene_set_mesh(rt_scene *s, const rt_mesh *mesh)
         rt_set_error("rt_scene_set_mesh: null scene");
         return RT_ERR_INVALID;
     }
+    { const int rc = rt_scene_quiesce(s); if (rc != RT_OK) return rc; }
+    s->epoch++;
     if (s->d_tris) RT_HIP(hipFree(s->d_tris));
     if (s->d_boxes) RT_HIP(hipFree(s->d_boxes));
     if (s->d_tri_idx) RT_HIP(hipFree(s->d_tri_idx));
@@ -789,7 +677,10 @@ extern "C" int rt_scene_set_texture(rt_scene *s, const float *r, const float *g,
         rt_set_error("rt_scene_set_texture: invalid argument");
         return RT_ERR_INVALID;
     }
-    const int rc = upload_planes(s->d_tex, r, g, b, w, h);
+    int rc = rt_scene_quiesce(s);
+    if (rc != RT_OK) return rc;
+    s->epoch++;
+    rc = upload_planes(s->d_tex, r, g, b, w, h);
     if (rc != RT_OK) return rc;
     s->tex_w = w;
     s->tex_h = h;
@@ -803,7 +694,10 @@ extern "C" int rt_scene_set_sky(rt_scene *s, const rt_sphere *box, const float *
         rt_set_error("rt_scene_set_sky: invalid argument");
         return RT_ERR_INVALID;
     }
-    const int rc = upload_planes(s->d_sky, r, g, b, w, h);
+    int rc = rt_scene_quiesce(s);
+    if (rc != RT_OK) return rc;
+    s->epoch++;
+    rc = upload_planes(s->d_sky, r, g, b, w, h);
     if (rc != RT_OK) return rc;
     s->sky_w = w;
     s->sky_h = h;
@@ -829,6 +723,7 @@ extern "C" int rt_scene_set_lights(rt_scene *s, const rt_light *lights, int n)
     s->n_lights = n;
     return RT_OK;
 }
+
 
 // ---------------------------------------------------------------------------
 // sample positions (build-defined extension; n = 1 is the reference's +0.5)
@@ -861,7 +756,128 @@ void rt_ray_origin(const rt_frame_desc *fd, float org[3])
     org[2] = ez + fd->cam.Org.z;
 }
 
-int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameConsts *fc)
+// dx and dy of kernel.cu:1624-1625 for every column, row and sample of a frame:
+//   dx = aspect*(2*(x+0.5)/(float)width) - 1,  dy = aspect*(2*(y+0.5)/(float)height)*((float)height/width) - 1
+// binary64 expressions (the literal 0.5) narrowed to float on assignment. They depend on the
+// camera in no way, so a moving camera re-uses them; a new size, aspect or sample count
+// rebuilds them (host, W + H divisions per sample) after waiting for the frames in flight.
+static int rt_scene_prepare_raygen(rt_scene *s, int width, int height, float aspect, int total)
+{
+    if (s->d_raygen && s->rg_w == width && s->rg_h == height && s->rg_total == total &&
+        memcmp(&s->rg_aspect, &aspect, sizeof aspect) == 0)
+        return RT_OK;
+    const int rc = rt_scene_quiesce(s);
+    if (rc != RT_OK) return rc;
+    const size_t need = (size_t)total * ((size_t)width + (size_t)height);
+    if (need > s->cap_raygen) {
+        if (s->d_raygen) RT_HIP(hipFree(s->d_raygen));
+        s->d_raygen = nullptr;
+        s->cap_raygen = 0;
+        RT_HIP(hipMalloc((void **)&s->d_raygen, sizeof(float) * need));
+        s->cap_raygen = need;
+    }
+    std::vector<float> h(need);
+    const double aspect_d = (double)aspect;
+    const double width_d = (double)(float)width, height_d = (double)(float)height;
+    const double hw_d = (double)((float)height / (float)width);
+    for (int k = 0; k < total; ++k) {
+        double ox, oy;
+        rt_sample_offset(k, total, &ox, &oy);
+        float *dx = h.data() + (size_t)k * width, *dy = h.data() + (size_t)total * width + (size_t)k * height;
+        for (int x = 0; x < width; ++x) {
+            const double tx_d = (2.0 * ((double)x + ox)) / width_d;
+            dx[x] = (float)(aspect_d * tx_d - 1.0);
+        }
+        for (int y = 0; y < height; ++y) {
+            const double ty_d = (2.0 * ((double)y + oy)) / height_d;
+            dy[y] = (float)((aspect_d * ty_d) * hw_d - 1.0);
+        }
+    }
+    RT_HIP(hipMemcpy(s->d_raygen, h.data(), sizeof(float) * need, hipMemcpyHostToDevice));
+    s->rg_w = width;
+    s->rg_h = height;
+    s->rg_total = total;
+    s->rg_aspect = aspect;
+    s->epoch++;
+    return RT_OK;
+}
+
+// margin of the fast texel-index path for a texture dimension of `size` texels (rt_kernels.hip:
+// sure_texel): approximation error RT_UV_DELTA plus the rounding of the two float products
+static float texel_margin(int size, float delta)
+{
+    return (float)size * (delta + 0x1.0p-22f) * 1.01f;
+}
+
+// Everything of the frame that lives in RtFrameAux (device memory): pure host computation.
+static void rt_build_frame_aux(const rt_scene *s, RtFrameAux *ax)
+{
+    memset(ax, 0, sizeof *ax);
+    // castLightRay sample constants, kernel.cu:1453-1454, 1462-1463
+    for (int j = 0; j < RT_SHADOW_SAMPLES; ++j) {
+        const float jf = (float)j / 10;
+        const float phi = jf * 2.f * 3.1415f;
+        ax->jf[j] = jf;
+        ax->jcos[j] = rtm::cosf_rt(phi);
+        ax->jsin[j] = rtm::sinf_rt(phi);
+    }
+    for (int i = 0; i < s->n_lights; ++i) {
+        const rt_light &l = s->lights[i];
+        RtLightDev &d = ax->lights[i];
+        d.px = l.pos.x; d.py = l.pos.y; d.pz = l.pos.z;
+        d.size = l.size;
+        d.r = l.r; d.g = l.g; d.b = l.b;
+        const float len = std::sqrt(l.pos.x * l.pos.x + l.pos.y * l.pos.y + l.pos.z * l.pos.z);
+        d.pos_len = len;
+        // a light at the origin has no beam axis: NaN makes the kernel skip culling
+        d.ux = len > 0 ? l.pos.x / len : NAN;
+        d.uy = len > 0 ? l.pos.y / len : NAN;
+        d.uz = len > 0 ? l.pos.z / len : NAN;
+    }
+    {
+        const int n_pad = (s->n_spheres + 63) & ~63;
+        const size_t per_light = (size_t)n_pad + 2 * (size_t)s->n_blocks;
+        const bool current = s->d_light_tabs && s->ltab_gen == s->sphere_gen && s->ltab_n_lights == s->n_lights;
+        for (int i = 0; i < RT_DEV_MAX_LIGHTS; ++i) {
+            const bool on = current && i < s->n_lights && s->ltab_valid[i];
+            ax->lsorted[i] = on ? reinterpret_cast<const float *>(s->d_light_tabs + per_light * i) : nullptr;
+            ax->lblocks[i] = on ? reinterpret_cast<const float *>(s->d_light_tabs + per_light * i + n_pad) : nullptr;
+        }
+    }
+    ax->sky_r = s->d_sky[0]; ax->sky_g = s->d_sky[1]; ax->sky_b = s->d_sky[2];
+    ax->sky_w = s->sky_w; ax->sky_h = s->sky_h;
+    ax->sky_cx = s->sky_c[0]; ax->sky_cy = s->sky_c[1]; ax->sky_cz = s->sky_c[2];
+    ax->sky_r2 = s->sky_radius * s->sky_radius;
+    ax->sky_mu_x = texel_margin(s->sky_w, 1.0e-6f);
+    ax->sky_mu_y = texel_margin(s->sky_h, 1.0e-6f);
+    ax->planes = s->d_planes;
+    ax->cubes = s->d_cubes;
+    ax->tris = s->d_tris;
+    ax->boxes = s->d_boxes;
+    ax->tri_idx = s->d_tri_idx;
+    ax->box_spheres = s->d_box_spheres;
+    ax->tri9 = s->d_tri9;
+}
+
+// Bring the device copy of RtFrameAux up to date (a camera move never changes it).
+static int rt_scene_sync_aux(rt_scene *s)
+{
+    RtFrameAux ax;
+    rt_build_frame_aux(s, &ax);
+    if (s->aux_valid && memcmp(&ax, &s->h_aux, sizeof ax) == 0) return RT_OK;
+    const int rc = rt_scene_quiesce(s);
+    if (rc != RT_OK) return rc;
+    if (!s->d_aux) RT_HIP(hipMalloc((void **)&s->d_aux, sizeof(RtFrameAux)));
+    RT_HIP(hipMemcpy(s->d_aux, &ax, sizeof ax, hipMemcpyHostToDevice));
+    s->h_aux = ax;
+    s->aux_valid = true;
+    s->epoch++;
+    return RT_OK;
+}
+
+// The by-value frame uniforms. Pure host computation: no device call, the scene is not
+// changed. `cones`: the eye-cone table the frame reads (its org must be the frame's), or null.
+int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, const float4 *cones, RtFrameConsts *fc)
 {
     if (!s || !fd) {
         rt_set_error("rt_scene_render: null scene or frame");
@@ -915,8 +931,9 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
     fc->spp = spp;
     fc->sample_base = o.sample_base;
     fc->sample_total = (float)total;
-    fc->accumulate = o.accumulate ? 1 : 0;
-    fc->resolve = ((fd->pixels || o.packed24) && o.resolve >= 0) ? 1 : 0;
+    fc->flags = (o.accumulate ? RT_FLAG_ACCUMULATE : 0) |
+                (((fd->pixels || o.packed24) && o.resolve >= 0) ? RT_FLAG_RESOLVE : 0) |
+                (o.force_slow_path ? RT_FLAG_FORCE_SLOW : 0) | (s->mesh_has_normals ? RT_FLAG_MESH_NORMALS : 0);
     fc->local_rows = y1 - y0;
     if (o.interleave_count > 1) {
         const int b = o.interleave_rows > 0 ? o.interleave_rows : 16;
@@ -934,28 +951,25 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
             rows += (fd->height - k * b < b) ? fd->height - k * b : b;
         fc->local_rows = rows;   // may be 0 (more ranks than row blocks): the launch is then skipped
     }
-    fc->force_slow = o.force_slow_path ? 1 : 0;
-    {   // timing experiments only: output is wrong when set
-        const char *ab = getenv("RT_ABLATE");
-        fc->ablate = ab ? atoi(ab) : 0;
-    }
+    fc->n_planes = s->n_planes;
+    fc->n_cubes = s->n_cubes;
+    fc->n_boxes = s->n_boxes;
+#ifdef RT_TUNING
+    fc->ablate = s->tune_ablate;   // timing experiments only: output is wrong when set
+#endif
 
-    // kernel.cu:1624-1625
-    const float aspect = fd->aspect;
-    fc->aspect_d = (double)aspect;
-    fc->width_d = (double)(float)fd->width;
-    fc->height_d = (double)(float)fd->height;
-    fc->hw_d = (double)((float)fd->height / (float)fd->width);
-    // kernel.cu:1629-1631: eyePos = (0,0,-1/aspect); dir - eyePos; eyePos + cam.Org
-    const float ez = -1.f / aspect;
+    // kernel.cu:1624-1625 through the raygen tables; :1629-1631: eyePos = (0,0,-1/aspect); dir - eyePos; eyePos + cam.Org
+    const bool rg = s->d_raygen && s->rg_w == fd->width && s->rg_h == fd->height && s->rg_total == total &&
+                    memcmp(&s->rg_aspect, &fd->aspect, sizeof(float)) == 0;
+    fc->dx_tab = rg ? s->d_raygen : nullptr;
+    fc->dy_tab = rg ? s->d_raygen + (size_t)total * fd->width : nullptr;
+    const float ez = -1.f / fd->aspect;
     fc->eye_nz = 0.f - ez;
-    {
-        float org[3];
-        rt_ray_origin(fd, org);
-        fc->org_x = org[0];
-        fc->org_y = org[1];
-        fc->org_z = org[2];
-    }
+    float org[3];
+    rt_ray_origin(fd, org);
+    fc->org_x = org[0];
+    fc->org_y = org[1];
+    fc->org_z = org[2];
     // camera::rotateDir, kernel.cu:249-250
     const float yawRad = (float)(fd->cam.Camyaw * (3.1415 / 180));
     const float pitchRad = (float)(fd->cam.Campitch * (3.1415 / 180));
@@ -963,58 +977,11 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
     fc->sin_pitch = rtm::sinf_rt(pitchRad);
     fc->cos_yaw = rtm::cosf_rt(yawRad);
     fc->sin_yaw = rtm::sinf_rt(yawRad);
-    for (int k = 0; k < total; ++k) rt_sample_offset(k, total, &fc->off_x[k], &fc->off_y[k]);
 
-    // castLightRay sample constants, kernel.cu:1453-1454, 1462-1463, 1538
-    {   // the device uses literals for this sequence (brightness_steps); re-derive and compare
-        static const float kSteps[RT_SHADOW_SAMPLES + 1] = {
-            0x0.0p+0f, 0x1.99999ap-4f, 0x1.99999ap-3f, 0x1.333334p-2f, 0x1.99999ap-2f, 0x1.000000p-1f,
-            0x1.333334p-1f, 0x1.666668p-1f, 0x1.99999cp-1f, 0x1.ccccd0p-1f, 0x1.000002p+0f};
-        float b = 0;
-        for (int j = 0; j <= RT_SHADOW_SAMPLES; ++j) {
-            fc->btab[j] = b;
-            if (b != kSteps[j]) {
-                rt_set_error("internal: brightness step table mismatch at %d", j);
-                return RT_ERR_INVALID;
-            }
-            b = (float)(b + 0.1);
-        }
-    }
-    for (int j = 0; j < RT_SHADOW_SAMPLES; ++j) {
-        const float jf = (float)j / 10;
-        const float phi = jf * 2.f * 3.1415f;
-        fc->jf[j] = jf;
-        fc->jcos[j] = rtm::cosf_rt(phi);
-        fc->jsin[j] = rtm::sinf_rt(phi);
-    }
-    for (int i = 0; i < s->n_lights; ++i) {
-        const rt_light &l = s->lights[i];
-        RtLightDev &d = fc->lights[i];
-        d.px = l.pos.x; d.py = l.pos.y; d.pz = l.pos.z;
-        d.size = l.size;
-        d.r = l.r; d.g = l.g; d.b = l.b;
-        const float len = std::sqrt(l.pos.x * l.pos.x + l.pos.y * l.pos.y + l.pos.z * l.pos.z);
-        d.pos_len = len;
-        // a light at the origin has no beam axis: NaN makes the kernel skip culling
-        d.ux = len > 0 ? l.pos.x / len : NAN;
-        d.uy = len > 0 ? l.pos.y / len : NAN;
-        d.uz = len > 0 ? l.pos.z / len : NAN;
-    }
     fc->tex_r = s->d_tex[0]; fc->tex_g = s->d_tex[1]; fc->tex_b = s->d_tex[2];
     fc->tex_w = s->tex_w; fc->tex_h = s->tex_h;
-    fc->sky_r = s->d_sky[0]; fc->sky_g = s->d_sky[1]; fc->sky_b = s->d_sky[2];
-    fc->sky_w = s->sky_w; fc->sky_h = s->sky_h;
-    fc->sky_cx = s->sky_c[0]; fc->sky_cy = s->sky_c[1]; fc->sky_cz = s->sky_c[2];
-    fc->sky_r2 = s->sky_radius * s->sky_radius;
-    {   // as quadratic() evaluates them on the device (no contraction: this file is built with -ffp-contract=off)
-        const float ocx = fc->org_x - fc->sky_cx, ocy = fc->org_y - fc->sky_cy, ocz = fc->org_z - fc->sky_cz;
-        fc->sky_ocx = ocx; fc->sky_ocy = ocy; fc->sky_ocz = ocz;
-        fc->sky_C = ((ocx * ocx + ocy * ocy) + ocz * ocz) - fc->sky_r2;
-    }
-    fc->planes = s->d_planes;
-    fc->cubes = s->d_cubes;
-    fc->n_planes = s->n_planes;
-    fc->n_cubes = s->n_cubes;
+    fc->tex_mu_x = texel_margin(s->tex_w, 5.0e-7f);   // RT_UV_DELTA of rt_kernels.hip
+    fc->tex_mu_y = texel_margin(s->tex_h, 5.0e-7f);
     {
         const int n_pad = (s->n_spheres + 63) & ~63;
         const float4 *base = s->d_spheres;
@@ -1022,28 +989,12 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, RtFrameCon
         fc->blocks = base ? reinterpret_cast<const float *>(base + s->n_spheres + n_pad) : nullptr;
         fc->orig_idx = base ? reinterpret_cast<const int *>(base + s->n_spheres + n_pad + s->n_blocks) : nullptr;
         fc->n_blocks = s->n_blocks;
-        const size_t per_light = (size_t)n_pad + 2 * (size_t)s->n_blocks;
-        const bool current = s->d_light_tabs && s->ltab_gen == s->sphere_gen && s->ltab_n_lights == s->n_lights;
-        for (int i = 0; i < RT_DEV_MAX_LIGHTS; ++i) {
-            const bool on = current && i < s->n_lights && s->ltab_valid[i];
-            fc->lsorted[i] = on ? reinterpret_cast<const float *>(s->d_light_tabs + per_light * i) : nullptr;
-            fc->lblocks[i] = on ? reinterpret_cast<const float *>(s->d_light_tabs + per_light * i + n_pad) : nullptr;
-        }
-        const float org[3] = {fc->org_x, fc->org_y, fc->org_z};
-        const bool cones = s->d_cone_tab && s->cone_valid && s->cone_gen == s->sphere_gen &&
-                           memcmp(org, s->cone_org, sizeof org) == 0;
-        fc->csorted = cones ? reinterpret_cast<const float *>(s->d_cone_tab) : nullptr;
-        fc->cblocks = cones ? reinterpret_cast<const float *>(s->d_cone_tab + n_pad) : nullptr;
-        fc->corig = cones ? reinterpret_cast<const int *>(s->d_cone_tab + n_pad + 2 * (size_t)s->n_blocks) : nullptr;
-        fc->cone_kcap = kConeKcap;
+        fc->csorted = cones ? reinterpret_cast<const float *>(cones) : nullptr;
+        fc->cblocks = cones ? reinterpret_cast<const float *>(cones + n_pad) : nullptr;
+        fc->corig = cones ? reinterpret_cast<const int *>(cones + n_pad + 2 * (size_t)s->n_blocks) : nullptr;
+        fc->cone_kcap = (float)RT_CONE_KCAP;
     }
-    fc->tris = s->d_tris;
-    fc->boxes = s->d_boxes;
-    fc->tri_idx = s->d_tri_idx;
-    fc->box_spheres = s->d_box_spheres;
-    fc->tri9 = s->d_tri9;
-    fc->n_boxes = s->n_boxes;
-    fc->mesh_has_normals = s->mesh_has_normals;
+    fc->aux = s->d_aux;
     fc->rgba = o.rgba;
     fc->packed = fd->pixels;
     fc->packed24 = (uint32_t *)o.packed24;
@@ -1066,36 +1017,108 @@ static int tile_from_opts(const rt_launch_opts &o, int *tile)
     return RT_OK;
 }
 
-extern "C" int rt_scene_render(rt_scene *s, const rt_frame_desc *fd, void *stream)
+// Which instantiation renders this frame (rt_kernels.hip: MODE, FEAT, TABLDS).
+int rt_frame_kernel_choice(const rt_scene *s, const rt_frame_desc *fd, RtKernelChoice *kc)
 {
-    RtFrameConsts fc;
-    int rc = RT_OK;
-    if (s && fd && fd->opts.cull != 0) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (stream) (void)hipStreamIsCapturing((hipStream_t)stream, &cs);
-        if (cs == hipStreamCaptureStatusNone) {   // a capture re-uses what rt_graph_capture prepared
-            rc = rt_scene_prepare_lights(s, (hipStream_t)stream);
-            if (rc != RT_OK) return rc;
-            float org[3];
-            rt_ray_origin(fd, org);
-            rc = rt_scene_prepare_eye(s, org, (hipStream_t)stream);
-            if (rc != RT_OK) return rc;
-        }
+    int rc = tile_from_opts(fd->opts, &kc->tile);
+    if (rc != RT_OK) return rc;
+    kc->cull = (fd->opts.cull == 0) ? 0 : 1;
+    kc->mode = fd->opts.stats ? (fd->opts.profile ? 3 : 1) : (fd->opts.force_slow_path ? 2 : 0);
+    kc->feat = s->n_boxes > 0 ? 2 : ((s->n_planes > 0 || s->n_cubes > 0) ? 1 : 0);
+    // whole-table LDS staging (north_star's first design, measured slower: DESIGN.md section 3)
+    // is opt-in per launch and only when the table fits next to the survivor lists
+    kc->table_lds = (fd->opts.table_lds == 1 && s->n_spheres <= kMaxSpheresLds) ? 1 : 0;
+#ifdef RT_TUNING
+    if (s->tune_table_lds && s->n_spheres <= kMaxSpheresLds) kc->table_lds = 1;
+#else
+    if (kc->mode == 3) {
+        rt_set_error("rt_scene_render: opts.profile (phase stamps) needs a tuning build of the library (make EXTRA=-DRT_TUNING)");
+        return RT_ERR_UNSUPPORTED;
     }
-    rc = rt_build_frame_consts(s, fd, &fc);
-    if (rc != RT_OK) return rc;
-    int tile = 8;
-    rc = tile_from_opts(fd->opts, &tile);
-    if (rc != RT_OK) return rc;
-    if (fc.local_rows == 0) return RT_OK;   // this rank owns no rows of the frame
-    if (fc.n_boxes > 0 && (tile != 8 || fd->opts.stats)) {
+#endif
+    if (kc->feat == 2 && (kc->tile != 8 || fd->opts.stats)) {
         rt_set_error("rt_scene_render: scenes with a triangle mesh render with the default tile and without stats");
         return RT_ERR_UNSUPPORTED;
     }
-    const int cull = (fd->opts.cull == 0) ? 0 : 1;
-    const int stats = fd->opts.stats ? (fd->opts.profile ? 2 : 1) : 0;
-    RT_HIP(rt_dev_launch_trace(&fc, s->d_spheres, tile, cull, stats, table_in_lds_for(s->n_spheres), (hipStream_t)stream));
+    if (fd->opts.stats && fd->opts.force_slow_path) {
+        rt_set_error("rt_scene_render: stats and force_slow_path exclude each other");
+        return RT_ERR_UNSUPPORTED;
+    }
     return RT_OK;
+}
+
+// Everything a frame needs on the device that is NOT the eye-cone table: per-light tables,
+// raygen tables, RtFrameAux. Host waits happen here, and only when something changed.
+int rt_scene_prepare_static(rt_scene *s, const rt_frame_desc *fd, hipStream_t stream)
+{
+    if (!s || !fd || fd->width <= 0 || fd->height <= 0) {
+        rt_set_error("rt_scene_render: null scene or bad frame");
+        return RT_ERR_INVALID;
+    }
+    int rc = RT_OK;
+    if (fd->opts.cull != 0) {
+        rc = rt_scene_prepare_lights(s, stream);
+        if (rc != RT_OK) return rc;
+    }
+    const int spp = fd->opts.spp > 0 ? fd->opts.spp : 1;
+    const int total = fd->opts.sample_total > 0 ? fd->opts.sample_total : spp;
+    if (total < 1 || total > RT_MAX_SPP) {
+        rt_set_error("rt_scene_render: bad sample total %d (max %d)", total, RT_MAX_SPP);
+        return RT_ERR_INVALID;
+    }
+    rc = rt_scene_prepare_raygen(s, fd->width, fd->height, fd->aspect, total);
+    if (rc != RT_OK) return rc;
+    return rt_scene_sync_aux(s);
+}
+
+extern "C" int rt_scene_render(rt_scene *s, const rt_frame_desc *fd, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!s || !fd) {
+        rt_set_error("rt_scene_render: null scene or frame");
+        return RT_ERR_INVALID;
+    }
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream) (void)hipStreamIsCapturing(stream, &cs);
+        if (cs != hipStreamCaptureStatusNone) {
+            rt_set_error("rt_scene_render: the stream is being captured; use rt_graph_capture, which records the frame as graph nodes");
+            return RT_ERR_UNSUPPORTED;
+        }
+    }
+    if (s->stage_busy) {   // a sphere-table upload enqueued on some stream: order this frame after it
+        if (hipEventQuery(s->stage_done) == hipSuccess) s->stage_busy = false;
+        else RT_HIP(hipStreamWaitEvent(stream, s->stage_done, 0));
+        (void)hipGetLastError();   // hipEventQuery reports "not ready" as an error
+    }
+    int rc = rt_scene_prepare_static(s, fd, stream);
+    if (rc != RT_OK) return rc;
+    int slot = -1;
+    if (fd->opts.cull != 0) {
+        float org[3];
+        rt_ray_origin(fd, org);
+        rc = rt_scene_prepare_eye(s, org, stream, &slot);
+        if (rc != RT_OK) return rc;
+    }
+    RtFrameConsts fc;
+    rc = rt_build_frame_consts(s, fd, slot >= 0 ? s->cones[slot].buf : nullptr, &fc);
+    if (rc != RT_OK) return rc;
+    RtKernelChoice kc;
+    rc = rt_frame_kernel_choice(s, fd, &kc);
+    if (rc != RT_OK) return rc;
+    if (fc.local_rows == 0) return RT_OK;   // this rank owns no rows of the frame
+    RT_HIP(rt_dev_launch_trace(&fc, s->d_spheres, kc.tile, kc.cull, kc.mode, kc.table_lds, kc.feat, stream));
+    return rt_scene_note_launch(s, stream, slot);
+}
+
+// For rt_graph.cpp: the scene's buffers a graph node needs.
+const float4 *rt_scene_sphere_table(const rt_scene *s) { return s->d_spheres; }
+int rt_scene_sphere_count(const rt_scene *s) { return s->n_spheres; }
+unsigned long long rt_scene_epoch(const rt_scene *s) { return s->epoch; }
+bool rt_scene_wants_eye_cones(const rt_scene *s, const float org[3]) { return eye_cones_wanted(s, org); }
+int rt_scene_build_eye_cones_host(rt_scene *s, const float org[3], float4 *buf, hipStream_t stream)
+{
+    return build_eye_cones_into(s, org, buf, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -1114,6 +1137,19 @@ struct ShimCache {
     float sky_radius = -1;
 };
 static ShimCache g_shim;
+
+// memManager::operator delete on something the shim has mirrored: the next launch re-uploads.
+static void shim_forget(const void *ptr)
+{
+    for (int i = 0; i < 3; ++i) {
+        if (ptr == g_shim.tex_key[i]) g_shim.tex_key[0] = g_shim.tex_key[1] = g_shim.tex_key[2] = nullptr;
+        if (ptr == g_shim.sky_key[i]) g_shim.sky_key[0] = g_shim.sky_key[1] = g_shim.sky_key[2] = nullptr;
+    }
+    if (ptr == g_shim.mesh_key) {
+        g_shim.mesh_key = nullptr;
+        g_shim.mesh_polys = g_shim.mesh_boxes = -1;
+    }
+}
 
 extern "C" void rt_invalidate_textures(void)
 {
@@ -1258,6 +1294,18 @@ extern "C" int rt_debug_math(int op, const float *a, const float *b, float *out,
     return RT_OK;
 }
 
+extern "C" int rt_debug_shortcuts(int what, unsigned seed, long long n, unsigned long long out[4])
+{
+    if (what < 0 || what > 2 || !out || n < 0) return RT_ERR_INVALID;
+    DevBuf<unsigned long long> d;
+    int rc = d.alloc(4);
+    if (rc != RT_OK) return rc;
+    RT_HIP(hipMemset(d.p, 0, sizeof(unsigned long long) * 4));
+    RT_HIP(rt_dev_launch_dbg_shortcuts(what, seed, n, d.p, nullptr));
+    RT_HIP(hipMemcpy(out, d.p, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
 extern "C" int rt_debug_intersect(const rt_sphere *spheres, const rt_ray *rays, int n, int *hit, float *t)
 {
     if (n <= 0 || !spheres || !rays || !hit || !t) return RT_ERR_INVALID;
@@ -1285,16 +1333,16 @@ extern "C" int rt_debug_light(const rt_sphere *spheres, int n_spheres, const rt_
     rt_scene sc;
     sc.lights[0] = *light;
     sc.n_lights = 1;
-    sc.have_sky = true;
-    rt_frame_desc fd;
-    memset(&fd, 0, sizeof fd);
-    fd.width = fd.height = 1;
-    fd.aspect = 1.f;
-    uint32_t dummy;
-    fd.pixels = &dummy;
-    RtFrameConsts fc;
-    int rc = rt_build_frame_consts(&sc, &fd, &fc);
+    RtFrameAux ax;
+    rt_build_frame_aux(&sc, &ax);
+    DevBuf<RtFrameAux> dax;
+    int rc = dax.alloc(1);
     if (rc != RT_OK) return rc;
+    RT_HIP(hipMemcpy(dax.p, &ax, sizeof ax, hipMemcpyHostToDevice));
+    RtFrameConsts fc;
+    memset(&fc, 0, sizeof fc);
+    fc.n_lights = 1;
+    fc.aux = dax.p;
     fc.n_spheres = n_spheres;
     std::vector<float4> tab(n_spheres ? n_spheres : 1);
     if (n_spheres) pack_spheres(spheres, n_spheres, tab.data());

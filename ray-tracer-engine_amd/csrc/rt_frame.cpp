@@ -70,6 +70,10 @@ static rt_object *objs = nullptr;
 static rt_skybox *Skybox = nullptr;
 static float aspect = 0.f;
 
+// asset files (kernel.cu:1700, 1706, 1181: hard-coded C:\\ paths in the reference): set through
+// rt_config_set_assets(), else the environment of the APPLICATION SHELL (RT_OBJECT_TEXTURE,
+// RT_SKY_TEXTURE, RT_MESH_OBJ, read once in onStart), else the synthetic stand-ins
+static std::string cfg_object_texture, cfg_sky_texture, cfg_mesh_obj;
 static int cfg_sphere_count = 1024;      // the reference ships 0 (kernel.cu:1231); BASELINE configs set it
 static unsigned int cfg_seed = 1;        // un-seeded MSVC rand() starts from state 1
 
@@ -96,6 +100,13 @@ extern "C" int rt_config_set_seed(unsigned int seed)
     cfg_seed = seed;
     return RT_OK;
 }
+extern "C" int rt_config_set_assets(const char *object_texture, const char *sky_texture, const char *mesh_obj)
+{
+    cfg_object_texture = object_texture ? object_texture : "";
+    cfg_sky_texture = sky_texture ? sky_texture : "";
+    cfg_mesh_obj = mesh_obj ? mesh_obj : "";
+    return RT_OK;
+}
 extern "C" rt_camera *rt_config_camera(void) { return &cam; }
 extern "C" rt_light *rt_config_lights(int *count)
 {
@@ -104,9 +115,10 @@ extern "C" rt_light *rt_config_lights(int *count)
 }
 extern "C" double rt_last_frame_ms(void) { return fr.last_ms; }
 
-static const char *env_or(const char *name, const char *dflt)
+static std::string asset(const std::string &configured, const char *env_name, const char *dflt)
 {
-    const char *v = getenv(name);
+    if (!configured.empty()) return configured;
+    const char *v = getenv(env_name);
     return (v && *v) ? v : dflt;
 }
 
@@ -122,9 +134,10 @@ void onStart()
     objs->sphere_count = cfg_sphere_count;
     // loadMesh (kernel.cu:1181-1207): `mesh1 = new mesh(file)` -- here only when RT_MESH_OBJ names an
     // OBJ file (the reference's skull2.obj is not in its repository); cubes/planes stay empty as shipped
-    if (const char *obj_path = getenv("RT_MESH_OBJ")) {
-        if (*obj_path) {
-            objs->mesh1 = rt_mesh_load_obj(obj_path);
+    {
+        const std::string obj_path = asset(cfg_mesh_obj, "RT_MESH_OBJ", "");
+        if (!obj_path.empty()) {
+            objs->mesh1 = rt_mesh_load_obj(obj_path.c_str());
             if (!objs->mesh1) {
                 fprintf(stderr, "onStart: %s\n", rt_last_error());
                 rt_check(1, "mesh(file)", __FILE__, __LINE__);
@@ -134,7 +147,7 @@ void onStart()
     // spheres from the rand() replay
     objs->s1 = (rt_sphere *)calloc((size_t)(cfg_sphere_count > 0 ? cfg_sphere_count : 1), sizeof(rt_sphere));
     rt_generate_spheres(objs->s1, cfg_sphere_count, cfg_seed);
-    objs->texture = (rt_sprite *)new sprite(env_or("RT_OBJECT_TEXTURE", "synthetic:object"));
+    objs->texture = (rt_sprite *)new sprite(asset(cfg_object_texture, "RT_OBJECT_TEXTURE", "synthetic:object"));
     // sphereAllocMem, kernel.cu:1208-1212 (32 bytes per sphere, :1218-1220)
     objs->d_spheres = (rt_sphere *)rt_managed_alloc(sizeof(float) * 8 * (size_t)(cfg_sphere_count > 0 ? cfg_sphere_count : 1));
     if (objs->d_spheres && cfg_sphere_count > 0)
@@ -143,7 +156,7 @@ void onStart()
     // skybox(img, 10000), kernel.cu:1120-1123, 1700
     Skybox = (rt_skybox *)rt_managed_alloc(sizeof(rt_skybox));
     if (!Skybox) return;
-    Skybox->skyboxTex = (rt_sprite *)new sprite(env_or("RT_SKY_TEXTURE", "synthetic:sky"));
+    Skybox->skyboxTex = (rt_sprite *)new sprite(asset(cfg_sky_texture, "RT_SKY_TEXTURE", "synthetic:sky"));
     Skybox->box = (rt_sphere *)rt_managed_alloc(sizeof(rt_sphere));
     if (Skybox->box) rt_sphere_init(Skybox->box, 0, 0, 0, 10000);
 

@@ -31,7 +31,25 @@
 #include "rt_device.h"
 #include "rt_math.h"
 
+// Timing experiments (RT_ABLATE) exist in tuning builds only (make EXTRA=-DRT_TUNING, tools/variants.sh):
+// the product kernel has no such switch and the product library reads no environment.
+#ifdef RT_TUNING
+#define RT_ABL(bits) ((fc.ablate & (bits)) != 0)
+#else
+#define RT_ABL(bits) false
+#endif
+
 namespace {
+
+// RtFrameAux is read through the CONSTANT address space: the memory does not change while a
+// kernel runs, and a load from a wave-uniform address there is a scalar load (s_load into
+// SGPRs) wherever it stands -- as a plain global pointer the compiler has to assume the
+// kernel's own stores may alias it and uses per-lane vector loads into VGPRs.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const RtFrameAux __attribute__((address_space(4))) *AuxPtr;
+#else
+typedef const RtFrameAux *AuxPtr;   // host pass over this translation unit (device functions are only parsed there)
+#endif
 
 struct V3 {
     float x, y, z;
@@ -126,6 +144,152 @@ __device__ __forceinline__ V3 normalise_inplace(V3 &v)
         return v;
     }
     return V3{0.f, 0.f, 0.f};
+}
+
+// ---------------------------------------------------------------------------
+// The same normalise() -- and the same correctly rounded binary32 square root --
+// without the instructions that only matter outside the ordinary range.
+//
+// hipcc expands an IEEE `a / b` into v_div_scale (x2), v_rcp, four FMAs, a multiply,
+// v_div_fmas and v_div_fixup, and an IEEE sqrtf into a pre-scaling select, v_sqrt, the
+// one-ulp-down / one-ulp-up residual test and a class fix-up (see the disassembly of
+// normalise_inplace above: 55 instructions). Pre-scaling and fix-up only act on
+// denormal, huge, zero, infinite or NaN operands; for operands in an ordinary range
+// v_div_scale returns its operand unchanged and clears VCC, v_div_fmas is then a plain
+// FMA and v_div_fixup returns its first operand. lean_sqrt() and the division below are
+// those expansions with exactly these no-ops left out -- every remaining instruction is
+// the one the full expansion executes, on the same operands -- and the reciprocal
+// refinement (which depends on the divisor only) shared by the three quotients: 35
+// instructions. Lanes outside the safe range take the full IEEE expansion:
+//   every component >= 2^-48 in magnitude (so dot >= 2^-96, above sqrt's pre-scaling
+//   threshold, no quotient below 2^-68, no numerator the scaling would touch) and
+//   dot <= 2^40.
+// A zero component is "unsafe" (the lean sequence would lose the sign of -0).
+// tests/test_gpu_parity.py compares both functions with the IEEE ones exhaustively
+// (sqrt: every float of the range) and on 2^28 random vectors; the brute-force and
+// force-slow kernels keep the IEEE forms, so every cull-vs-brute comparison checks
+// them against each other as well.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float lean_sqrt(float x)   // x in [2^-96, 2^126]
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
+    const float su = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
+    const float rd = __builtin_fmaf(-sd, s, x);
+    const float ru = __builtin_fmaf(-su, s, x);
+    float r = (rd <= 0.f) ? sd : s;
+    r = (ru > 0.f) ? su : r;
+    return r;
+}
+
+struct LeanRcp {   // the divisor-only part of the division expansion
+    float d, r;
+    __device__ __forceinline__ explicit LeanRcp(float den) : d(den)
+    {
+        const float r0 = __builtin_amdgcn_rcpf(den);
+        const float e0 = __builtin_fmaf(-den, r0, 1.f);
+        r = __builtin_fmaf(e0, r0, r0);
+    }
+    __device__ __forceinline__ float divide(float n) const
+    {
+        const float q0 = n * r;
+        const float e1 = __builtin_fmaf(-d, q0, n);
+        const float q1 = __builtin_fmaf(e1, r, q0);
+        const float e2 = __builtin_fmaf(-d, q1, n);
+        return __builtin_fmaf(e2, r, q1);
+    }
+};
+
+template <bool LEAN>
+__device__ __forceinline__ V3 normalise_t(V3 &v)
+{
+    if constexpr (!LEAN) {
+        return normalise_inplace(v);
+    } else {
+        const float d2 = dot3(v, v);
+        const float amin = __builtin_fminf(__builtin_fminf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), __builtin_fabsf(v.z));
+        const bool safe = (amin >= 0x1.0p-48f) & (d2 <= 0x1.0p40f);   // false for a NaN anywhere
+        if (__builtin_expect(!safe, 0)) return normalise_inplace(v);
+        const LeanRcp rl(lean_sqrt(d2));
+        v.x = rl.divide(v.x);
+        v.y = rl.divide(v.y);
+        v.z = rl.divide(v.z);
+        return v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Texel index of a unit normal without binary64: castRay's (tx, ty) (kernel.cu:1402-1403)
+// only ever select a texel, c_index = (int)(ty*maxY)*maxX + (int)(tx*maxX) (kernel.cu:1653).
+// approx_sphere_uv() evaluates tx = (1 + atan2(n.z, n.x)/3.1415)/2 and ty = acos(n.y)/3.1415
+// in binary32 with absolute error below RT_UV_DELTA (budget: quotient after one Newton step
+// 0.5 ulp, degree-8 polynomial 1.2e-8 + ~1 ulp of evaluation, all quadrant reconstruction done
+// in units of the RESULT so that no step rounds at the magnitude of pi: 1.7e-7 for tx, 2.6e-7
+// for ty; rt_debug_uv measures it on the device and tests/test_gpu_parity.py asserts half of
+// RT_UV_DELTA). A lane is "sure" when both products tx*W, ty*H stay at least
+// mu = size * (RT_UV_DELTA + 2^-22) away from every integer (the second term covers the
+// rounding of the two float products): then truncation gives the same column and row as the
+// exact value would. Unsure lanes (about 5 % of the 8x8 tiles contain one at 512x512) -- and
+// anything negative or NaN -- take the exact binary64 path.
+// ---------------------------------------------------------------------------
+#define RT_UV_DELTA 5.0e-7f
+
+// atan(a) for a in [0, 1], absolute error < 1.0e-7 (Chebyshev fit of atan(sqrt(s))/sqrt(s), degree 8 in s)
+__device__ __forceinline__ float atan01(float a)
+{
+    const float s = a * a;
+    float p = 0x1.73776ap-9f;
+    p = __builtin_fmaf(p, s, -0x1.0639f6p-6f);
+    p = __builtin_fmaf(p, s, 0x1.5ce0b0p-5f);
+    p = __builtin_fmaf(p, s, -0x1.330372p-4f);
+    p = __builtin_fmaf(p, s, 0x1.b3ae74p-4f);
+    p = __builtin_fmaf(p, s, -0x1.22de60p-3f);
+    p = __builtin_fmaf(p, s, 0x1.997232p-3f);
+    p = __builtin_fmaf(p, s, -0x1.5554a2p-2f);
+    p = __builtin_fmaf(p, s, 1.0f);
+    return a * p;
+}
+
+// angle(y, x) * scale for y >= 0 given as magnitudes: returns scale * atan2(ay, x) in [0, scale*pi],
+// reconstructed in units of the result. k_half = scale*pi/2, k_full = scale*pi (both rounded once).
+__device__ __forceinline__ float scaled_angle(float ay, float x, float scale, float k_half, float k_full)
+{
+    const float ax = __builtin_fabsf(x);
+    const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
+    const float r = __builtin_amdgcn_rcpf(mx);
+    const float a0 = mn * r;
+    const float a = __builtin_fmaf(__builtin_fmaf(-mx, a0, mn), r, a0);   // mn / mx to half an ulp (NaN for 0/0)
+    float u = atan01(a) * scale;
+    u = (ay > ax) ? k_half - u : u;
+    u = (x < 0.f) ? k_full - u : u;
+    return u;
+}
+
+__device__ __forceinline__ void approx_sphere_uv(V3 n, float &tx, float &ty)
+{
+    constexpr double kC = 1.0 / 3.1415, kPiD = 3.14159265358979323846;
+    // tx = 0.5 + sign(n.z) * atan2(|n.z|, n.x) / (2 * 3.1415)
+    const float u = scaled_angle(__builtin_fabsf(n.z), n.x, (float)(0.5 * kC), (float)(0.25 * kPiD * kC), (float)(0.5 * kPiD * kC));
+    tx = __builtin_signbit(n.z) ? 0.5f - u : 0.5f + u;
+    // ty = atan2(sqrt((1 - y)(1 + y)), y) / 3.1415; the root to about an ulp (one Newton step)
+    const float q = (1.f - n.y) * (1.f + n.y);
+    const float s0 = __builtin_amdgcn_sqrtf(q);
+    const float rs = __builtin_amdgcn_rsqf(q);
+    const float sy = (q > 0.f) ? __builtin_fmaf(__builtin_fmaf(-s0, s0, q), 0.5f * rs, s0) : 0.f;
+    ty = scaled_angle(sy, n.y, (float)kC, (float)(0.5 * kPiD * kC), (float)(kPiD * kC));
+    if (!(__builtin_fabsf(n.y) <= 1.f)) ty = __builtin_nanf("");   // the exact function returns NaN there
+}
+
+// Column/row selection with certainty: returns the linear index row*w + col when both products are
+// clear of every integer by the margins, else -1 (the caller evaluates the exact expressions).
+__device__ __forceinline__ int sure_texel(float tx, float ty, int w, int h, float mu_x, float mu_y)
+{
+    const float px = tx * (float)w, py = ty * (float)h;
+    const float fx = __builtin_floorf(px), fy = __builtin_floorf(py);
+    const float rx = px - fx, ry = py - fy;
+    const bool sure = (rx > mu_x) & (rx < 1.f - mu_x) & (ry > mu_y) & (ry < 1.f - mu_y) & (fx >= 0.f) & (fy >= 0.f) &
+                      (fx <= 16384.f) & (fy <= 16384.f);
+    return sure ? (int)fy * w + (int)fx : -1;
 }
 
 // float -> int of the implicit conversions at kernel.cu:1653, 1157-1158, 1682:
@@ -595,6 +759,7 @@ __device__ __forceinline__ int build_box_list(const float4 *__restrict__ bsph, i
 // ---------------------------------------------------------------------------
 // castLightRay's sample construction, kernel.cu:1438-1468 (exact)
 // ---------------------------------------------------------------------------
+template <bool LEAN>
 struct ShadowChain {
     V3 toL;            // keeps being re-normalised in place by the reference
     bool stable;       // an iteration leaves toL as it found it: every later iteration repeats this one
@@ -606,7 +771,7 @@ struct ShadowChain {
     {
         // toL = normalise(l.pos - start), kernel.cu:1438
         toL = V3{lpos.x - start.x, lpos.y - start.y, lpos.z - start.z};
-        normalise_inplace(toL);
+        normalise_t<LEAN>(toL);
         stable = false;
         fixed1 = false;
         angle = 0.f;
@@ -623,9 +788,9 @@ struct ShadowChain {
             if (__all(stable)) break;
             if (!stable) {
                 const V3 tin = toL;
-                normalise_inplace(toL);
+                normalise_t<LEAN>(toL);
                 const V3 mid = toL;
-                normalise_inplace(toL);
+                normalise_t<LEAN>(toL);
                 // unchanged by the pair, or a fixed point of normalise(): toL has its final value
                 stable = ((toL.x == tin.x) && (toL.y == tin.y) && (toL.z == tin.z)) ||
                          ((toL.x == mid.x) && (toL.y == mid.y) && (toL.z == mid.z));
@@ -638,31 +803,31 @@ struct ShadowChain {
     // (kernel.cu:1465-1466). Once two more normalisations leave toL
     // bit-identical, every later iteration reproduces the same values, so the
     // block is skipped (70 % of lanes are stable after j = 0, 99.6 % after j = 1).
-    __device__ __forceinline__ V3 direction(const RtFrameConsts &fc, const RtLightDev &L, V3 start, int j,
-                                            const double *atab = nullptr)
+    __device__ __forceinline__ V3 direction(AuxPtr ax, bool force_slow, const RtLightDev &L,
+                                            V3 start, int j, const double *atab = nullptr)
     {
         const V3 lpos{L.px, L.py, L.pz};
-        if (!stable || fc.force_slow) {
+        if (!stable || force_slow) {
             const V3 tin = toL;
             // P = cross(toL, (0,1,0)), kernel.cu:1444
             const V3 P{toL.y * 0.f - toL.z * 1.f, toL.z * 0.f - toL.x * 0.f, toL.x * 1.f - toL.y * 0.f};
             V3 e0{(lpos.x + P.x * L.size) - start.x, (lpos.y + P.y * L.size) - start.y,
                   (lpos.z + P.z * L.size) - start.z};
-            const V3 toEdge = normalise_inplace(e0);                       // kernel.cu:1450
+            const V3 toEdge = normalise_t<LEAN>(e0);                       // kernel.cu:1450
             angle = rtm::cosf_rt(dot3(toL, toEdge) * 2.f);                 // kernel.cu:1451
             // The rest depends on toL only through its next two in-place normalisations. Once
             // normalise() maps toL to itself (`fixed1`, 96 % of the lanes that are not `stable`
             // after the first iteration) those leave it -- and the axis, nAngle and the matrix
             // -- as they are: this iteration only had a new `angle` to compute, the next ones
             // repeat it.
-            if (!fixed1 || fc.force_slow) {
+            if (!fixed1 || force_slow) {
                 // axis = normalise(cross((0,0,1), normalise(toL))), kernel.cu:1465
-                const V3 n1 = normalise_inplace(toL);
+                const V3 n1 = normalise_t<LEAN>(toL);
                 const V3 mid = toL;
                 V3 ax0{0.f * n1.z - 1.f * n1.y, 1.f * n1.x - 0.f * n1.z, 0.f * n1.y - 0.f * n1.x};
-                const V3 axis = normalise_inplace(ax0);
+                const V3 axis = normalise_t<LEAN>(ax0);
                 // nAngle = acosf(dot(normalise(toL), (0,0,1))), kernel.cu:1466
-                const V3 n2 = normalise_inplace(toL);
+                const V3 n2 = normalise_t<LEAN>(toL);
                 const float nAngle = rtm::acosf_rt((n2.x * 0.f + n2.y * 0.f) + n2.z * 1.f, atab);
                 float sn, cs;
                 rtm::sincosf_rt(nAngle, sn, cs);
@@ -684,15 +849,18 @@ struct ShadowChain {
                 stable = true;
             }
         }
-        const float z = fc.jf[j] * (1.0f - angle) + angle;                 // kernel.cu:1453
-        const float sq = __builtin_sqrtf(1.f - z * z);                     // kernel.cu:1462-1463
-        const float x = sq * fc.jcos[j];
-        const float y = sq * fc.jsin[j];
+        const float z = ax->jf[j] * (1.0f - angle) + angle;                // kernel.cu:1453
+        const float zz = 1.f - z * z;
+        float sq;                                                          // kernel.cu:1462-1463
+        if (LEAN && __builtin_expect(zz >= 0x1.0p-96f, 1)) sq = lean_sqrt(zz);   // zz <= 1
+        else sq = __builtin_sqrtf(zz);
+        const float x = sq * ax->jcos[j];
+        const float y = sq * ax->jsin[j];
         // multiply(rot, {x,y,z}), kernel.cu:123-125
         const V3 rv{(x * m00 + y * m10) + z * m20, (x * m01 + y * m11) + z * m21,
                     (x * m02 + y * m12) + z * m22};
         V3 nd{lpos.x - rv.x, lpos.y - rv.y, lpos.z - rv.z};
-        return normalise_inplace(nd);                                      // kernel.cu:1468
+        return normalise_t<LEAN>(nd);                                      // kernel.cu:1468
     }
 };
 
@@ -724,12 +892,30 @@ __device__ __forceinline__ void shadow_test(const RayK &sr, float4 s, bool &shad
 // ---------------------------------------------------------------------------
 // the frame kernel
 // ---------------------------------------------------------------------------
-// STATS: 0 = product kernel, 1 = work counters, 2 = per-phase cycle stamps
-// (s_memtime; a diagnostic build whose run time is never quoted).
-template <int TW, bool CULL, int STATS, bool TABLDS, bool MESH = false>
-__global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_PER_SIMD) void rt_trace_tiles(const RtFrameConsts fc,
+// MODE: 0 = product kernel, 1 = work counters, 2 = every exactness-preserving shortcut off
+// (rt_launch_opts.force_slow_path: tests), 3 = per-phase cycle stamps (s_memtime; RT_TUNING
+// builds only, run time never quoted).
+// FEAT: 0 = spheres only (the reference's default scene and every BASELINE config), 1 = with
+// the cube / plane branches of castRay and castLightRay, 2 = with those and the triangle mesh.
+// Each is its own instantiation so that the sphere-only kernel carries neither the code nor
+// the live scalars of primitives that are not there.
+// MULTI: the launch may take several samples per pixel (rt_launch_opts.spp > 1). The
+// one-sample kernel has no sample loop: 74 -> 22 spilled scalars and 15 fewer vector registers.
+template <int TW, bool CULL, int MODE, bool TABLDS, int FEAT = 0, bool MULTI = true>
+__global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (!MULTI && FEAT < 2 && !TABLDS) ? RT_MIN_WAVES_ONE_SAMPLE : RT_MIN_WAVES_PER_SIMD) void rt_trace_tiles(const RtFrameConsts fc,
                                                                      const float4 *__restrict__ spheres)
 {
+    constexpr int STATS = (MODE == 1) ? 1 : (MODE == 3) ? 2 : 0;
+    constexpr bool force_slow = (MODE == 2);
+    constexpr bool MESH = (FEAT == 2);
+    constexpr bool PRIMS = (FEAT >= 1);   // cubes and planes may be present
+    // the culling kernels take every exactness-preserving shortcut (lean normalise/sqrt, fast
+    // texel index); the brute-force and force-slow ones evaluate everything the long way
+#ifdef RT_NO_LEAN
+    constexpr bool LEAN = false;
+#else
+    constexpr bool LEAN = CULL && !force_slow;
+#endif
     constexpr int TH = 64 / TW;
     // Waves per workgroup: RT_WAVES_PER_WG share one staged table (TABLDS); with the table left
     // in global memory nothing is shared, and one-wave workgroups fill the SIMDs best
@@ -743,6 +929,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
     const int wave = tid >> 6;
     const int n = fc.n_spheres;
     const int n_pad = (n + 63) & ~63;
+    const AuxPtr ax = (AuxPtr)(uintptr_t)fc.aux;   // lights, sample constants, sky, planes/cubes, mesh (device memory)
 
     // ---- stage the sphere table into LDS (coalesced 16 B/lane) ----
     float4 *tab = lds;
@@ -792,7 +979,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
     unsigned long long hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = 0;
-    const bool span_only = (fc.ablate & 512) != 0;   // no inner stamps: near-real wave durations
+    const bool span_only = RT_ABL(512);   // no inner stamps: near-real wave durations
     const unsigned long long rt_begin = (STATS == 2) ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz
     auto phase = [&](int k, bool last = false) {   // charge the cycles since the previous stamp to phase k
         if (STATS == 2 && (k < 0 || last || !span_only)) {
@@ -808,15 +995,17 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
 
     float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f;
 
-    for (int sample = 0; sample < fc.spp; ++sample) {
+    const int n_samples = MULTI ? fc.spp : 1;
+    for (int sample = 0; sample < n_samples; ++sample) {
         // ================= primary ray, kernel.cu:1624-1631 =================
+        // dx, dy of kernel.cu:1624-1625 (binary64 expressions of the column resp. the row) come
+        // from the frame's tables, evaluated by the host with the reference's operations; lanes
+        // beyond the frame edge read the last column / row (their pixels are never stored)
         const int sidx = fc.sample_base + sample;
-        const double tx_d = (2.0 * ((double)px + fc.off_x[sidx])) / fc.width_d;
-        const double ty_d = (2.0 * ((double)py + fc.off_y[sidx])) / fc.height_d;
-        const float dx = (float)(fc.aspect_d * tx_d - 1.0);
-        const float dy = (float)((fc.aspect_d * ty_d) * fc.hw_d - 1.0);
+        const float dx = fc.dx_tab[sidx * fc.width + (px < fc.width ? px : fc.width - 1)];
+        const float dy = fc.dy_tab[sidx * fc.height + (py < fc.height ? py : fc.height - 1)];
         V3 dir{dx, dy, fc.eye_nz};   // (dx,dy,0) - (0,0,-1/aspect)
-        normalise_inplace(dir);
+        normalise_t<LEAN>(dir);
         // camera::rotateDir, kernel.cu:252-257 (cos/sin hoisted to the host)
         V3 D;
         {
@@ -869,7 +1058,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                 }
                 if (STATS == 1) st_entries += (unsigned long long)(c <= RT_LIST_CAP ? c : n);
                 if (MESH) {
-                    const int cb = build_box_list(reinterpret_cast<const float4 *>(fc.box_spheres), fc.n_boxes, myboxes, myboxes + RT_BOX_CAP, b, lane);
+                    const int cb = build_box_list(reinterpret_cast<const float4 *>(ax->box_spheres), fc.n_boxes, myboxes, myboxes + RT_BOX_CAP, b, lane);
                     if (cb <= RT_BOX_CAP) {
                         pb_use_list = true;
                         pbcount = cb;
@@ -888,17 +1077,17 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
             // triangles through the flat list of leaf boxes, kernel.cu:1293-1328 (before
             // the spheres, as there): a lane tests a leaf's triangles iff its ray hits the box
             const V3 inv{1.f / D.x, 1.f / D.y, 1.f / D.z};
-            for (int jj = 0; jj < ((fc.ablate & 2048) ? 0 : pbcount); ++jj) {
+            for (int jj = 0; jj < (RT_ABL(2048) ? 0 : pbcount); ++jj) {
                 const int j = pb_use_list ? myboxes[jj] : jj;
-                const RtBoxDev bx = fc.boxes[j];
+                const RtBoxDev bx = ax->boxes[j];
                 const bool bh = box_intersect(bx, O, inv);
-                if (__any(bh) && !(fc.ablate & 1024)) {
+                if (__any(bh) && !RT_ABL(1024)) {
                     // the leaf's vertices, seven triangles (63 floats) per coalesced load, staged in LDS
                     // and broadcast from there: one memory round trip per seven triangles instead of
                     // two dependent scalar loads per triangle
                     for (int base = 0; base < bx.len; base += 7) {
                         const int cnt = bx.len - base < 7 ? bx.len - base : 7;
-                        mytri[lane] = fc.tri9[(size_t)(bx.start + base) * 9 + lane];   // the array is padded by 64 floats
+                        mytri[lane] = ax->tri9[(size_t)(bx.start + base) * 9 + lane];   // the array is padded by 64 floats
                         wave_lds_sync();
                         for (int i = 0; i < cnt; ++i) {
                             const float *tv = mytri + 9 * i;
@@ -936,8 +1125,8 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
             pcur = primary_entry(e + 1 < pcount ? e + 1 : e);   // one entry in flight
             const Quad q = quadratic(pr, s);
             bool need = (q.disc >= 0.f);
-            if (!fc.force_slow) need = need && !(q.h > 0.f && q.disc < q.BB * RT_BEHIND_FACTOR);
-            if (fc.force_slow) need = true;
+            if (!force_slow) need = need && !(q.h > 0.f && q.disc < q.BB * RT_BEHIND_FACTOR);
+            if (force_slow) need = true;
             if (__any(need)) {
                 if (need) {
                     float t;
@@ -954,7 +1143,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
             }
             if (STATS == 1) { st_primary += __popcll(__ballot(valid)); st_slots += 64; }
             // every remaining entry returns t >= its bound >= the next entry's bound
-            if (p_front_to_back && e + 1 < pcount && !fc.force_slow) {
+            if (p_front_to_back && e + 1 < pcount && !force_slow) {
                 const float lb_next = plbs[e + 1];
                 if (__all(!valid || nt < lb_next)) break;
             }
@@ -962,10 +1151,10 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
         if (CULL) wave_lds_sync();   // the list is rebuilt below
         // cubes (kernel.cu:1344-1356) then planes (:1359-1372): few, tested exhaustively;
         // for a plane hit hc* carries the plane's normal instead of a centre
-        if (fc.n_cubes > 0) {
+        if (PRIMS && fc.n_cubes > 0) {
             const V3 inv{1.f / D.x, 1.f / D.y, 1.f / D.z};
             for (int i = 0; i < fc.n_cubes; ++i) {
-                const RtCubeDev c = fc.cubes[i];
+                const RtCubeDev c = ax->cubes[i];
                 float t;
                 if (cube_intersect(c, O, inv, t) && t < nt) {
                     nt = t;
@@ -974,8 +1163,8 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                 }
             }
         }
-        for (int i = 0; i < fc.n_planes; ++i) {
-            const RtPlaneDev p = fc.planes[i];
+        for (int i = 0; i < (PRIMS ? fc.n_planes : 0); ++i) {
+            const RtPlaneDev p = ax->planes[i];
             float t;
             if (plane_intersect(p, O, D, t) && t < nt) {
                 nt = t;
@@ -990,23 +1179,18 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
         // ================= miss: skybox::getFColor, kernel.cu:1147-1166 =================
         int sky_idx = -1;
         if (valid && !hit) {
-            const float4 sk = make_float4(fc.sky_cx, fc.sky_cy, fc.sky_cz, fc.sky_r2);
-            // quadratic(pr, sk) with its ray-independent part (oc, C) taken from the frame constants:
-            // left to the compiler it is hoisted out of the sample loop into VGPRs and spilled
-            Quad q;
-            q.h = (pr.dx * fc.sky_ocx + pr.dy * fc.sky_ocy) + pr.dz * fc.sky_ocz;
-            q.B = 2.f * q.h;
-            q.BB = q.B * q.B;
-            q.disc = q.BB - pr.a4 * fc.sky_C;
+            const float4 sk = make_float4(ax->sky_cx, ax->sky_cy, ax->sky_cz, ax->sky_r2);
+            const Quad q = quadratic(pr, sk);
             float t;
             intersect_tail(pr, q, t);   // the boolean is ignored there, t is used as left
             const V3 hp{O.x + D.x * t, O.y + D.y * t, O.z + D.z * t};
             V3 nrm{hp.x - sk.x, hp.y - sk.y, hp.z - sk.z};
-            normalise_inplace(nrm);
-            const int ix = f2i((1.f + rtm::atan2f_rt(nrm.z, nrm.x, myatan) / 3.1415f) * 0.5f * (float)fc.sky_w);
-            const int iy = f2i(rtm::acosf_rt(nrm.y, myatan) / 3.1415f * (float)fc.sky_h);
-            int idx = iy * fc.sky_w + ix;
-            const int last = fc.sky_w * fc.sky_h - 1;
+            normalise_t<LEAN>(nrm);
+            const int sky_w = ax->sky_w, sky_h = ax->sky_h;
+            const int ix = f2i((1.f + rtm::atan2f_rt(nrm.z, nrm.x, myatan) / 3.1415f) * 0.5f * (float)sky_w);
+            const int iy = f2i(rtm::acosf_rt(nrm.y, myatan) / 3.1415f * (float)sky_h);
+            int idx = iy * sky_w + ix;
+            const int last = sky_w * sky_h - 1;
             idx = idx < 0 ? 0 : (idx > last ? last : idx);   // documented clamp (reference is UB there)
             sky_idx = idx;
         }
@@ -1017,15 +1201,16 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
         if (hit) {
             const V3 new_org{O.x + D.x * nt, O.y + D.y * nt, O.z + D.z * nt};
             float tx = 0.5f, ty = 0.5f;   // plane, kernel.cu:1413-1414
+            int ci_fast = -1;             // texel index already known for sure (sphere / cube hits of the culling kernels)
             V3 hp = new_org;              // what start_O is offset from
             if (MESH && hkind == 0) {     // triangle, kernel.cu:1378-1393
-                const RtTriDev *tp = fc.tris + fc.tri_idx[htri];
+                const RtTriDev *tp = ax->tris + ax->tri_idx[htri];
                 const float w0 = 1 - hnu - hnv;
-                if (fc.mesh_has_normals) {
+                if (fc.flags & RT_FLAG_MESH_NORMALS) {
                     normal = V3{(tp->vn[0] * w0 + tp->vn[3] * hnu) + tp->vn[6] * hnv,
                                 (tp->vn[1] * w0 + tp->vn[4] * hnu) + tp->vn[7] * hnv,
                                 (tp->vn[2] * w0 + tp->vn[5] * hnu) + tp->vn[8] * hnv};
-                    normalise_inplace(normal);
+                    normalise_t<LEAN>(normal);
                 } else {
                     normal = V3{tp->n[0], tp->n[1], tp->n[2]};
                 }
@@ -1034,13 +1219,21 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                 // new_org = add(normal, add(Org, Dir * nt)): displaced by the whole normal
                 hp = V3{normal.x + new_org.x, normal.y + new_org.y, normal.z + new_org.z};
                 hcx = hcy = hcz = 0.f;    // one group for all triangle hits of the tile
-            } else if (hkind == 2) {      // plane, kernel.cu:1407-1416: the normal as stored
+            } else if (PRIMS && hkind == 2) {      // plane, kernel.cu:1407-1416: the normal as stored
                 normal = V3{hcx, hcy, hcz};
             } else {                      // sphere / cube, kernel.cu:1396-1405, 1418-1425
                 normal = V3{new_org.x - hcx, new_org.y - hcy, new_org.z - hcz};
-                normalise_inplace(normal);
-                if (fc.ablate & 8) {
+                normalise_t<LEAN>(normal);
+                if (RT_ABL(8)) {
                     tx = normal.x; ty = normal.y;
+                } else if (LEAN && !RT_ABL(4096)) {
+                    float ux, uy;
+                    approx_sphere_uv(normal, ux, uy);
+                    ci_fast = sure_texel(ux, uy, fc.tex_w, fc.tex_h, fc.tex_mu_x, fc.tex_mu_y);
+                    if (__builtin_expect(ci_fast < 0, 0)) {
+                        tx = (float)((1.0 + rtm::div_by_3p1415((double)rtm::atan2f_rt(normal.z, normal.x, myatan))) * 0.5);
+                        ty = (float)rtm::div_by_3p1415((double)rtm::acosf_rt(normal.y, myatan));
+                    }
                 } else {
                     // the literals 1, 3.1415, 0.5 make these binary64 expressions
                     // kernel.cu:1402-1403; "/ 3.1415" in binary64 through div_by_3p1415 (same bits)
@@ -1049,6 +1242,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                 }
             }
             int ci = f2i(ty * (float)fc.tex_h) * fc.tex_w + f2i(tx * (float)fc.tex_w);
+            if (ci_fast >= 0) ci = ci_fast;
             const int last = fc.tex_w * fc.tex_h - 1;
             ci = ci < 0 ? 0 : (ci > last ? last : ci);       // documented clamp
             tr = fc.tex_r[ci];
@@ -1062,11 +1256,11 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
         phase(3);
         float fr = 0.f, fg = 0.f, fb = 0.f;   // this sample's colour (sky texel on a miss)
         if (sky_idx >= 0) {
-            fr = fc.sky_r[sky_idx];
-            fg = fc.sky_g[sky_idx];
-            fb = fc.sky_b[sky_idx];
+            fr = ax->sky_r[sky_idx];
+            fg = ax->sky_g[sky_idx];
+            fb = ax->sky_b[sky_idx];
         }
-        if (__any(hit) && !(fc.ablate & 16)) {
+        if (__any(hit) && !RT_ABL(16)) {
             // A tile that straddles a silhouette sees several spheres at different
             // depths; one beam around all of their shadow rays would be fat and its
             // survivor list long. So the hit lanes are processed in groups that share
@@ -1108,7 +1302,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                 g_r2 = uniform(wave_max(inc ? __builtin_fmaf(ox, ox, __builtin_fmaf(oy, oy, oz * oz)) : 0.f));
             }
             for (int li = 0; li < fc.n_lights; ++li) {
-                const RtLightDev L = fc.lights[li];
+                const RtLightDev L = ax->lights[li];
                 const V3 lpos{L.px, L.py, L.pz};
 
                 // toL = normalise(l.pos - start), kernel.cu:1438 -- here only to ~1e-6 (fast
@@ -1131,7 +1325,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                 // runs the reference's loops as written and is what tests compare with.)
                 bool lit = inc;
                 bool zero_ok = false;   // brightness 0 adds exactly nothing for this lane
-                if (CULL && !fc.force_slow) {
+                if (CULL && !force_slow) {
                     const float a0 = dot3(normal, toL);
                     const float fin = (L.r * tr) * (L.g * tg) * (L.b * tb);   // finite iff all six are
                     zero_ok = (__builtin_fabsf(fin) < __builtin_inff()) && (__builtin_fabsf(a0) < 1.0e30f);
@@ -1152,7 +1346,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                     b.ux = L.ux; b.uy = L.uy; b.uz = L.uz;
                     // approximate sample directions from toL (fast math; padded below)
                     float smax2 = 0.f;
-                    if (fc.ablate & 32) smax2 = 0.01f;
+                    if (RT_ABL(32)) smax2 = 0.01f;
                     else {
                         const float c = toL.z;
                         const float sn = __builtin_amdgcn_sqrtf(__builtin_fmaxf(1.f - c * c, 0.f));
@@ -1211,16 +1405,16 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                     b.smin = -b.r0;
                     b.smax = b.r0;
                     phase(4);
-                    if (fc.ablate & 4) { ok = false; scount = 0; }
+                    if (RT_ABL(4)) { ok = false; scount = 0; }
                     if (ok) {
                         // One sphere in front of the whole beam shadows all 10 samples of
                         // every lit lane: unshadowed = 0, b = 0, and the light adds exactly
                         // nothing -- the sample construction and the tests are skipped.
-                        const bool may_skip = !fc.force_slow && !(fc.ablate & 64) && __all(!lit || zero_ok);
-                        const float4 *lsorted = reinterpret_cast<const float4 *>(fc.lsorted[li]);
+                        const bool may_skip = !force_slow && !RT_ABL(64) && __all(!lit || zero_ok);
+                        const float4 *lsorted = reinterpret_cast<const float4 *>(ax->lsorted[li]);
                         const int cb = lsorted ? build_list2<STATS, TABLDS, true, false, 1>(
                                                      tab, fc, n, mylist, mykeys, myblks, b, lane, st_cull, lsorted,
-                                                     reinterpret_cast<const float4 *>(fc.lblocks[li]))
+                                                     reinterpret_cast<const float4 *>(ax->lblocks[li]))
                                                : build_list2<STATS, TABLDS, true, false>(tab, fc, n, mylist, mykeys, myblks, b,
                                                                                          lane, st_cull);
                         const int c = cb & 0x3fffffff;
@@ -1230,7 +1424,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                             continue;
                         }
                         if (MESH) {
-                            const int cbx = build_box_list(reinterpret_cast<const float4 *>(fc.box_spheres), fc.n_boxes, myboxes, myboxes + RT_BOX_CAP, b, lane);
+                            const int cbx = build_box_list(reinterpret_cast<const float4 *>(ax->box_spheres), fc.n_boxes, myboxes, myboxes + RT_BOX_CAP, b, lane);
                             if (cbx <= RT_BOX_CAP) {
                                 sb_use_list = true;
                                 sbcount = cbx;
@@ -1253,7 +1447,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
 
                 phase(5);
                 // ---------- the 10 samples, kernel.cu:1442-1540 (exact) ----------
-                ShadowChain chain;
+                ShadowChain<LEAN> chain;
                 chain.begin(lpos, start);
                 int unshadowed = 0;
                 // A short list whose every sphere lies behind every ray of the beam (for
@@ -1264,8 +1458,8 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                 // needed for kernel.cu:1541. Typically the list is just the sphere the
                 // tile itself lies on.
                 bool all_clear = false;
-                if (CULL && (!MESH || (sb_use_list && sbcount == 0)) && s_use_list && scount <= 4 && !fc.force_slow &&
-                    !(fc.ablate & 128) && (fc.n_planes | fc.n_cubes) == 0) {
+                if (CULL && (!MESH || (sb_use_list && sbcount == 0)) && s_use_list && scount <= 4 && !force_slow &&
+                    !RT_ABL(128) && (!PRIMS || (fc.n_planes | fc.n_cubes) == 0)) {
                     bool clear = true;
                     for (int e = 0; e < scount; ++e) {
                         const float4 sp = mylist[e];
@@ -1286,8 +1480,8 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                 // The samples will be walked: put the likeliest occluders first -- the spheres that
                 // reach farthest across the beam's axis (distance from the axis minus radius) -- so
                 // that the any-hit loops end sooner. An any-hit does not depend on the order.
-                if (CULL && s_use_list && !all_clear && scount > 2 && scount <= 64 && !fc.force_slow &&
-                    !(fc.ablate & 256)) {
+                if (CULL && s_use_list && !all_clear && scount > 2 && scount <= 64 && !force_slow &&
+                    !RT_ABL(256)) {
                     float *kbuf = reinterpret_cast<float *>(myblks);
                     float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
                     float key = 0.f;
@@ -1312,19 +1506,19 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                 }
 #pragma unroll 1
                 for (int j = 0; j < (all_clear ? 0 : RT_SHADOW_SAMPLES); ++j) {
-                    const V3 new_dir = (fc.ablate & 2) ? chain.toL : chain.direction(fc, L, start, j, myatan);
+                    const V3 new_dir = RT_ABL(2) ? chain.toL : chain.direction(ax, force_slow, L, start, j, myatan);
                     const RayK sr = make_ray(start, new_dir);
                     phase(6);
                     // any-hit over the list, kernel.cu:1501-1510
                     bool shadowed = !lit;   // lanes outside the group (or unlit) are simply done
-                    const int scount_j = (fc.ablate & 1) ? 0 : scount;
+                    const int scount_j = RT_ABL(1) ? 0 : scount;
                     if (scount_j > 0) {
                         const float4 *gtab = CULL ? reinterpret_cast<const float4 *>(fc.sorted) : spheres;
                         float4 cur = entry_at<TABLDS>(s_use_list, mylist, tab, gtab, 0);
                         for (int e = 0; e < scount_j; ++e) {
                             const float4 nxt = entry_at<TABLDS>(s_use_list, mylist, tab, gtab,
                                                                 e + 1 < scount_j ? e + 1 : e);   // one entry in flight
-                            shadow_test(sr, cur, shadowed, fc.force_slow != 0);
+                            shadow_test(sr, cur, shadowed, force_slow);
                             cur = nxt;
                             if (STATS == 1) { st_shadow += __popcll(__ballot(lit)); st_slots += 64; }
                             if (__all(shadowed)) break;
@@ -1336,12 +1530,12 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                         const V3 inv{1.f / new_dir.x, 1.f / new_dir.y, 1.f / new_dir.z};
                         for (int bjj = 0; bjj < sbcount; ++bjj) {
                             const int bj = sb_use_list ? myboxes[bjj] : bjj;
-                            const RtBoxDev bx = fc.boxes[bj];
+                            const RtBoxDev bx = ax->boxes[bj];
                             const bool bh = !shadowed && box_intersect(bx, start, inv);
                             if (__any(bh)) {
                                 for (int base = 0; base < bx.len; base += 7) {
                                     const int cnt = bx.len - base < 7 ? bx.len - base : 7;
-                                    mytri[lane] = fc.tri9[(size_t)(bx.start + base) * 9 + lane];
+                                    mytri[lane] = ax->tri9[(size_t)(bx.start + base) * 9 + lane];
                                     wave_lds_sync();
                                     for (int i = 0; i < cnt; ++i) {
                                         const float *tv = mytri + 9 * i;
@@ -1356,17 +1550,17 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
                         }
                     }
                     // planes (kernel.cu:1511-1523) then cubes (:1524-1536), any-hit
-                    if ((fc.n_planes | fc.n_cubes) != 0 && !__all(shadowed)) {
+                    if (PRIMS && (fc.n_planes | fc.n_cubes) != 0 && !__all(shadowed)) {
                         for (int i = 0; i < fc.n_planes; ++i) {
                             float t;
-                            if (!shadowed && plane_intersect(fc.planes[i], start, new_dir, t)) shadowed = true;
+                            if (!shadowed && plane_intersect(ax->planes[i], start, new_dir, t)) shadowed = true;
                             if (__all(shadowed)) break;
                         }
                         if (fc.n_cubes > 0 && !__all(shadowed)) {
                             const V3 inv{1.f / new_dir.x, 1.f / new_dir.y, 1.f / new_dir.z};
                             for (int i = 0; i < fc.n_cubes; ++i) {
                                 float t;
-                                if (!shadowed && cube_intersect(fc.cubes[i], start, inv, t)) shadowed = true;
+                                if (!shadowed && cube_intersect(ax->cubes[i], start, inv, t)) shadowed = true;
                                 if (__all(shadowed)) break;
                             }
                         }
@@ -1399,10 +1593,10 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
     // ================= write-back =================
     if (valid) {
         const size_t o = out_idx;
-        float w = (float)fc.spp;
+        float w = (float)n_samples;
         if (fc.rgba) {
             float4 *dst = reinterpret_cast<float4 *>(fc.rgba) + o;
-            if (fc.accumulate) {
+            if (fc.flags & RT_FLAG_ACCUMULATE) {
                 const float4 old = *dst;
                 acc_r = old.x + acc_r;
                 acc_g = old.y + acc_g;
@@ -1411,7 +1605,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
             }
             *dst = make_float4(acc_r, acc_g, acc_b, w);
         }
-        if (fc.packed && fc.resolve) {
+        if (fc.packed && (fc.flags & RT_FLAG_RESOLVE)) {
             // mean over the frame's samples (x/1.0f is exact, so 1 spp is the
             // reference's rgbToInt(fr*254, fg*254, fb*254), kernel.cu:1682/1688)
             float mr = acc_r, mg = acc_g, mb = acc_b;
@@ -1423,7 +1617,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), RT_MIN_WAVES_P
             fc.packed[o] = rgb_to_int(f2i(mr * 254.f), f2i(mg * 254.f), f2i(mb * 254.f));
         }
     }
-    if (fc.packed24 && fc.resolve) {   // wave-uniform; all lanes take part in the quad exchange
+    if (fc.packed24 && (fc.flags & RT_FLAG_RESOLVE)) {   // wave-uniform; all lanes take part in the quad exchange
         float mr = acc_r, mg = acc_g, mb = acc_b;
         if (fc.sample_total != 1.f) {
             mr = acc_r / fc.sample_total;
@@ -1520,12 +1714,14 @@ __global__ void rt_dbg_light(const RtFrameConsts fc, const float4 *tab, const fl
     const int k = live ? i : 0;
     const V3 start{starts[3 * k + 0], starts[3 * k + 1], starts[3 * k + 2]};
     const V3 normal{normals[3 * k + 0], normals[3 * k + 1], normals[3 * k + 2]};
-    const RtLightDev L = fc.lights[light_index];
-    ShadowChain chain;
+    const AuxPtr ax = (AuxPtr)(uintptr_t)fc.aux;
+    const bool force_slow = (fc.flags & RT_FLAG_FORCE_SLOW) != 0;
+    const RtLightDev L = ax->lights[light_index];
+    ShadowChain<false> chain;
     chain.begin(V3{L.px, L.py, L.pz}, start);
     int unshadowed = 0;
     for (int j = 0; j < RT_SHADOW_SAMPLES; ++j) {
-        const V3 d = chain.direction(fc, L, start, j);
+        const V3 d = chain.direction(ax, force_slow, L, start, j);
         if (live) {
             dirs[30 * i + 3 * j + 0] = d.x;
             dirs[30 * i + 3 * j + 1] = d.y;
@@ -1534,7 +1730,7 @@ __global__ void rt_dbg_light(const RtFrameConsts fc, const float4 *tab, const fl
         const RayK sr = make_ray(start, d);
         bool shadowed = !live;
         for (int e = 0; e < fc.n_spheres; ++e) {
-            shadow_test(sr, tab[e], shadowed, fc.force_slow != 0);
+            shadow_test(sr, tab[e], shadowed, force_slow);
             if (__all(shadowed)) break;
         }
         if (!shadowed) unshadowed += 1;
@@ -1546,97 +1742,201 @@ __global__ void rt_dbg_light(const RtFrameConsts fc, const float4 *tab, const fl
     }
 }
 
+// The shortcuts of the culling kernels against the long forms (rt_debug_shortcuts, tests only).
+__device__ __forceinline__ unsigned hash32(unsigned x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float unit_float(unsigned h) { return (float)(h >> 8) * 0x1.0p-24f; }   // [0, 1)
+
+__global__ void rt_dbg_shortcuts(int what, unsigned seed, long long n, unsigned long long *out)
+{
+    __shared__ double atab[16];
+    if (threadIdx.x < 16) atab[threadIdx.x] = kAtanEighth[threadIdx.x];
+    __syncthreads();
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    unsigned long long bad = 0, accepted = 0, wrong = 0;
+    float emax_x = 0.f, emax_y = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned h0 = hash32((unsigned)i * 3u + seed), h1 = hash32((unsigned)i * 3u + 1u + seed * 7919u),
+                       h2 = hash32((unsigned)i * 3u + 2u + seed * 104729u), h3 = hash32(h0 ^ (unsigned)(i >> 32) ^ 0x9e3779b9u);
+        if (what == 0) {
+            // vectors of every scale: unit-ish, tiny, huge, with zero / denormal components now and then
+            const int e = (int)(h3 % 61u) - 30 + ((h3 >> 8) % 7u == 0 ? ((h3 >> 12) % 2u ? 60 : -60) : 0);
+            const float sc = __builtin_ldexpf(1.f, e);
+            V3 a{(unit_float(h0) * 2.f - 1.f) * sc, (unit_float(h1) * 2.f - 1.f) * sc, (unit_float(h2) * 2.f - 1.f) * sc};
+            if ((h3 >> 20) % 13u == 0) a.x = 0.f;
+            if ((h3 >> 24) % 17u == 0) a.y = -0.f;
+            if ((h3 >> 28) % 5u == 0) a.z = a.z * 0x1.0p-100f;
+            V3 b = a;
+            const V3 ra = normalise_inplace(a);
+            const V3 rb = normalise_t<true>(b);
+            const bool same = __builtin_bit_cast(unsigned, a.x) == __builtin_bit_cast(unsigned, b.x) &&
+                              __builtin_bit_cast(unsigned, a.y) == __builtin_bit_cast(unsigned, b.y) &&
+                              __builtin_bit_cast(unsigned, a.z) == __builtin_bit_cast(unsigned, b.z) &&
+                              __builtin_bit_cast(unsigned, ra.x) == __builtin_bit_cast(unsigned, rb.x) &&
+                              __builtin_bit_cast(unsigned, ra.y) == __builtin_bit_cast(unsigned, rb.y) &&
+                              __builtin_bit_cast(unsigned, ra.z) == __builtin_bit_cast(unsigned, rb.z);
+            if (!same) bad += 1;
+        } else if (what == 2) {
+            // unit normals: uniform on the sphere, plus clusters at the poles and the seams
+            float z = unit_float(h0) * 2.f - 1.f, phi = unit_float(h1) * 6.2831853f;
+            if ((h3 & 15u) == 0) z = 1.f - unit_float(h2) * 1.0e-6f;
+            if ((h3 & 15u) == 1) z = -1.f + unit_float(h2) * 1.0e-6f;
+            if ((h3 & 15u) == 2) phi = (float)((h2 >> 4) & 7u) * 0.78539816f + (unit_float(h2) - 0.5f) * 1.0e-6f;
+            const float r = __builtin_sqrtf(__builtin_fmaxf(1.f - z * z, 0.f));
+            V3 nrm{r * __builtin_cosf(phi), z, r * __builtin_sinf(phi)};
+            normalise_inplace(nrm);
+            const float tx = (float)((1.0 + rtm::div_by_3p1415((double)rtm::atan2f_rt(nrm.z, nrm.x, atab))) * 0.5);
+            const float ty = (float)rtm::div_by_3p1415((double)rtm::acosf_rt(nrm.y, atab));
+            float ux, uy;
+            approx_sphere_uv(nrm, ux, uy);
+            const float ex = __builtin_fabsf(ux - tx), ey = __builtin_fabsf(uy - ty);
+            // a NaN approximation (0/0 at the poles, where the exact atan2 is defined) is simply never "sure"
+            if (ex == ex) emax_x = __builtin_fmaxf(emax_x, ex);
+            if (ey == ey) emax_y = __builtin_fmaxf(emax_y, ey);
+            const int w = 512, hh = 512;
+            const float mu = (float)w * (RT_UV_DELTA + 0x1.0p-22f) * 1.01f;
+            const int cf = sure_texel(ux, uy, w, hh, mu, mu);
+            if (cf >= 0) {
+                accepted += 1;
+                if (cf != f2i(ty * (float)hh) * w + f2i(tx * (float)w)) wrong += 1;
+            }
+        }
+    }
+    if (what == 1) {   // every float of [2^-96, 2^40]: bit patterns 0x0F800000 .. 0x53800000
+        const unsigned lo = 0x0F800000u, hi = 0x53800000u;
+        for (unsigned long long b = lo + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b <= hi; b += (unsigned long long)stride) {
+            const float x = __builtin_bit_cast(float, (unsigned)b);
+            if (__builtin_bit_cast(unsigned, lean_sqrt(x)) != __builtin_bit_cast(unsigned, __builtin_sqrtf(x))) bad += 1;
+        }
+    }
+    if (bad) atomicAdd(&out[0], bad);
+    if (what == 2) {
+        atomicMax(&out[0], (unsigned long long)__builtin_bit_cast(unsigned, emax_x));
+        atomicMax(&out[1], (unsigned long long)__builtin_bit_cast(unsigned, emax_y));
+        if (accepted) atomicAdd(&out[2], accepted);
+        if (wrong) atomicAdd(&out[3], wrong);
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
-// host-side launchers (called from rt_engine.cpp)
+// host-side launchers (called from rt_engine.cpp / rt_graph.cpp)
 // ---------------------------------------------------------------------------
-// Raise the dynamic-LDS limit of every instantiation once (a single workgroup may
-// use the whole 160 KiB). Not a stream operation, so it must not run inside a
-// graph capture: rt_graph_capture() calls this first.
+// The instantiations that exist. Tile widths other than 8 and whole-table LDS staging are
+// tuning / test dimensions: TABLDS exists for the default tile only (other tiles read the
+// table from global memory whatever was asked), mesh scenes (FEAT 2) render with the default
+// tile in modes 0 and 2, and MODE 3 (phase stamps) exists in RT_TUNING builds only.
+typedef void (*RtTraceFn)(const RtFrameConsts, const float4 *);
+
+template <int TW, bool CULL, bool TABLDS, bool MULTI>
+static RtTraceFn trace_fn_mode_feat(int mode, int feat)
+{
+    if (feat == 2) {
+        if constexpr (TW == 8) {
+            if (mode == 0) return rt_trace_tiles<TW, CULL, 0, TABLDS, 2, MULTI>;
+            if (mode == 2) return rt_trace_tiles<TW, CULL, 2, TABLDS, 2, MULTI>;
+        }
+        return nullptr;
+    }
+    switch (mode) {
+    case 0: return feat ? rt_trace_tiles<TW, CULL, 0, TABLDS, 1, MULTI> : rt_trace_tiles<TW, CULL, 0, TABLDS, 0, MULTI>;
+    case 1: return feat ? rt_trace_tiles<TW, CULL, 1, TABLDS, 1, MULTI> : rt_trace_tiles<TW, CULL, 1, TABLDS, 0, MULTI>;
+    case 2: return feat ? rt_trace_tiles<TW, CULL, 2, TABLDS, 1, MULTI> : rt_trace_tiles<TW, CULL, 2, TABLDS, 0, MULTI>;
+#ifdef RT_TUNING
+    case 3: return feat ? rt_trace_tiles<TW, CULL, 3, TABLDS, 1, MULTI> : rt_trace_tiles<TW, CULL, 3, TABLDS, 0, MULTI>;
+#endif
+    default: return nullptr;
+    }
+}
+
+template <int TW>
+static RtTraceFn trace_fn_tw(int cull, int mode, int table_in_lds, int feat, int multi)
+{
+    if constexpr (TW == 8) {   // the default tile: every combination, with and without the sample loop
+        if (table_in_lds) {
+            if (multi) return cull ? trace_fn_mode_feat<TW, true, true, true>(mode, feat) : trace_fn_mode_feat<TW, false, true, true>(mode, feat);
+            return cull ? trace_fn_mode_feat<TW, true, true, false>(mode, feat) : trace_fn_mode_feat<TW, false, true, false>(mode, feat);
+        }
+        if (!multi) return cull ? trace_fn_mode_feat<TW, true, false, false>(mode, feat) : trace_fn_mode_feat<TW, false, false, false>(mode, feat);
+    }
+    return cull ? trace_fn_mode_feat<TW, true, false, true>(mode, feat) : trace_fn_mode_feat<TW, false, false, true>(mode, feat);
+}
+
+static RtTraceFn trace_fn(int tile_w, int cull, int mode, int table_in_lds, int feat, int multi)
+{
+    switch (tile_w) {
+    case 8: return trace_fn_tw<8>(cull, mode, table_in_lds, feat, multi);
+    case 16: return trace_fn_tw<16>(cull, mode, table_in_lds, feat, multi);
+    case 32: return trace_fn_tw<32>(cull, mode, table_in_lds, feat, multi);
+    case 64: return trace_fn_tw<64>(cull, mode, table_in_lds, feat, multi);
+    default: return nullptr;
+    }
+}
+
+// Raise the dynamic-LDS limit of the instantiations that stage the whole table (a single
+// workgroup may use the whole 160 KiB). Not a stream operation: it runs once, outside any
+// stream capture or graph construction.
 extern "C" hipError_t rt_dev_prepare(void)
 {
     static bool done = false;
     if (done) return hipSuccess;
-    hipError_t e = hipSuccess;
-#define RT_ATTR(TW, C, S)                                                                          \
-    if (e == hipSuccess)                                                                           \
-        e = hipFuncSetAttribute((const void *)rt_trace_tiles<TW, C, S, true>,                     \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-#define RT_ATTR_TW(TW) RT_ATTR(TW, true, 0); RT_ATTR(TW, false, 0); RT_ATTR(TW, true, 1); RT_ATTR(TW, false, 1); RT_ATTR(TW, true, 2); RT_ATTR(TW, false, 2)
-    RT_ATTR_TW(8);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void *)rt_trace_tiles<8, true, 0, true, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void *)rt_trace_tiles<8, false, 0, true, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    RT_ATTR_TW(16);
-    RT_ATTR_TW(32);
-    RT_ATTR_TW(64);
-#undef RT_ATTR_TW
-#undef RT_ATTR
-    if (e == hipSuccess) done = true;
-    return e;
+    for (int cull = 0; cull < 2; ++cull)
+        for (int mode = 0; mode < 4; ++mode)
+            for (int feat = 0; feat < 3; ++feat)
+                for (int multi = 0; multi < 2; ++multi) {
+                    const RtTraceFn fn = trace_fn(8, cull, mode, 1, feat, multi);
+                    if (!fn) continue;
+                    const hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    if (e != hipSuccess) return e;
+                }
+    done = true;
+    return hipSuccess;
 }
 
-extern "C" hipError_t rt_dev_launch_trace(const RtFrameConsts *fc, const float4 *spheres, int tile_w,
-                                          int cull, int stats, int table_in_lds, hipStream_t stream)
+// Everything a launch of the frame kernel needs besides its two arguments. table_in_lds is
+// honoured for the default tile only. hipErrorNotSupported: no such instantiation.
+extern "C" hipError_t rt_dev_trace_config(const RtFrameConsts *fc, int tile_w, int cull, int mode, int table_in_lds, int feat,
+                                          const void **func, dim3 *grid, dim3 *block, unsigned *lds_bytes)
 {
-    if (fc->n_boxes > 0 && (tile_w != 8 || stats != 0)) return hipErrorNotSupported;   // mesh scenes: default tile only
+    if (tile_w != 8) table_in_lds = 0;
+    const RtTraceFn fn = trace_fn(tile_w, cull, mode, table_in_lds, feat, fc->spp > 1 ? 1 : 0);
+    if (!fn) return hipErrorNotSupported;
     const int n_pad = (fc->n_spheres + 63) & ~63;
     const int wpw = table_in_lds ? RT_WAVES_PER_WG : 1;   // as WPW in the kernel
-    const size_t lds_bytes = (size_t)((table_in_lds ? n_pad : 0) + wpw * RT_LIST_CAP) * sizeof(float4) +
-                             (size_t)wpw * RT_LIST_CAP * sizeof(int) +   // list positions (primary order)
-                             (size_t)wpw * 16 * sizeof(float) +          // brightness table per wave
-                             (size_t)wpw * 64 * sizeof(int) +            // marked blocks of a culling pass
-                             (size_t)wpw * 16 * sizeof(double) +         // atan(k/8) per wave
-                             (fc->n_boxes > 0 ? (size_t)wpw * (RT_BOX_CAP + 128) * sizeof(int) : 0);
-    const int band_h = fc->local_rows;
+    *lds_bytes = (unsigned)((size_t)((table_in_lds ? n_pad : 0) + wpw * RT_LIST_CAP) * sizeof(float4) +
+                            (size_t)wpw * RT_LIST_CAP * sizeof(int) +   // list positions (primary order)
+                            (size_t)wpw * 16 * sizeof(float) +          // brightness table per wave
+                            (size_t)wpw * 64 * sizeof(int) +            // marked blocks of a culling pass
+                            (size_t)wpw * 16 * sizeof(double) +         // atan(k/8) per wave
+                            (feat == 2 ? (size_t)wpw * (RT_BOX_CAP + 128) * sizeof(int) : 0));
     const int th = 64 / tile_w;
     const int wgx = (tile_w <= 16 && wpw >= 2) ? 2 : 1;
     const int wgy = wpw / wgx;
-    dim3 grid((fc->width + tile_w * wgx - 1) / (tile_w * wgx), (band_h + th * wgy - 1) / (th * wgy));
-    dim3 block(64 * wpw);
-    {
-        const hipError_t pe = rt_dev_prepare();
-        if (pe != hipSuccess) return pe;
-    }
+    *grid = dim3((fc->width + tile_w * wgx - 1) / (tile_w * wgx), (fc->local_rows + th * wgy - 1) / (th * wgy));
+    *block = dim3(64 * wpw);
+    *func = (const void *)fn;
+    return rt_dev_prepare();
+}
 
-    if (fc->n_boxes > 0) {
-        if (cull && table_in_lds)
-            hipLaunchKernelGGL((rt_trace_tiles<8, true, 0, true, true>), grid, block, lds_bytes, stream, *fc, spheres);
-        else if (cull)
-            hipLaunchKernelGGL((rt_trace_tiles<8, true, 0, false, true>), grid, block, lds_bytes, stream, *fc, spheres);
-        else if (table_in_lds)
-            hipLaunchKernelGGL((rt_trace_tiles<8, false, 0, true, true>), grid, block, lds_bytes, stream, *fc, spheres);
-        else
-            hipLaunchKernelGGL((rt_trace_tiles<8, false, 0, false, true>), grid, block, lds_bytes, stream, *fc, spheres);
-        return hipGetLastError();
-    }
-#define RT_LAUNCH(TW, C, S)                                                                        \
-    do {                                                                                           \
-        if (table_in_lds)                                                                          \
-            hipLaunchKernelGGL((rt_trace_tiles<TW, C, S, true>), grid, block, lds_bytes, stream, *fc, spheres);  \
-        else                                                                                       \
-            hipLaunchKernelGGL((rt_trace_tiles<TW, C, S, false>), grid, block, lds_bytes, stream, *fc, spheres); \
-    } while (0)
-#define RT_LAUNCH_TW(TW)                                                                           \
-    do {                                                                                           \
-        if (stats == 2) { if (cull) RT_LAUNCH(TW, true, 2); else RT_LAUNCH(TW, false, 2); }        \
-        else if (stats == 1) { if (cull) RT_LAUNCH(TW, true, 1); else RT_LAUNCH(TW, false, 1); }   \
-        else { if (cull) RT_LAUNCH(TW, true, 0); else RT_LAUNCH(TW, false, 0); }                   \
-    } while (0)
+extern "C" hipError_t rt_dev_launch_trace(const RtFrameConsts *fc, const float4 *spheres, int tile_w, int cull, int mode,
+                                          int table_in_lds, int feat, hipStream_t stream)
+{
+    const void *func = nullptr;
+    dim3 grid, block;
+    unsigned lds_bytes = 0;
+    const hipError_t ce = rt_dev_trace_config(fc, tile_w, cull, mode, table_in_lds, feat, &func, &grid, &block, &lds_bytes);
+    if (ce != hipSuccess) return ce;
+    hipLaunchKernelGGL((RtTraceFn)func, grid, block, lds_bytes, stream, *fc, spheres);
+    return hipGetLastError();
+}
 
-    switch (tile_w) {
-    case 8: RT_LAUNCH_TW(8); break;
-    case 16: RT_LAUNCH_TW(16); break;
-    case 32: RT_LAUNCH_TW(32); break;
-    case 64: RT_LAUNCH_TW(64); break;
-    default: return hipErrorInvalidValue;
-    }
-#undef RT_LAUNCH_TW
-#undef RT_LAUNCH
+extern "C" hipError_t rt_dev_launch_dbg_shortcuts(int what, unsigned seed, long long n, unsigned long long *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rt_dbg_shortcuts, dim3(4096), dim3(256), 0, stream, what, seed, n, out);
     return hipGetLastError();
 }
 

@@ -1,0 +1,439 @@
+// rt_tables.hip -- the culling tables of a device-resident scene: orderings of the sphere
+// table {cx,cy,cz,radius*radius} with conservative block bounds (see rt_device.h and DESIGN.md
+// section 4). None of them can change a pixel: a table only decides which spheres the exact
+// tests of rt_kernels.hip get to see, and every bound is padded so that a sphere left out is
+// one whose exact test (/root/reference/kernel.cu:293-354) would have returned false.
+//
+//   build_sorted_blocks   3-D Morton order, bounding spheres      host, when the list changes
+//   build_light_columns   per light: order ACROSS its axis        host, when a light or the list changes
+//   eye cones             order by direction as seen from the     DEVICE (rt_eye_cones_launch), every time
+//                         ray origin, cones from the origin       the camera moves: one 1024-thread
+//                                                                 workgroup, bitonic sort in LDS; the
+//                                                                 host version is the fallback for
+//                                                                 lists beyond RT_EYE_DEVICE_MAX
+// The reference moves its camera every frame (checkKey, kernel.cu:1716-1759): that must not
+// cost a host-side sort, a blocking upload and a device synchronisation per frame.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <utility>
+#include <vector>
+
+#include "rt_device.h"
+#include "rt_tables.h"
+
+// ---------------------------------------------------------------------------
+// shared host / device pieces
+// ---------------------------------------------------------------------------
+#define RT_HDI __host__ __device__ inline
+
+RT_HDI unsigned morton16(unsigned v)
+{
+    v &= 0xffffu;
+    v = (v | (v << 8)) & 0x00ff00ffu;
+    v = (v | (v << 4)) & 0x0f0f0f0fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+static unsigned morton10(unsigned v)
+{
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+RT_HDI void oct_map(const double d[3], double *u, double *v)
+{
+    const double s = fabs(d[0]) + fabs(d[1]) + fabs(d[2]);
+    double x = d[0] / s, y = d[1] / s;
+    if (d[2] < 0) {
+        const double ox = (1 - fabs(y)) * (x >= 0 ? 1 : -1), oy = (1 - fabs(x)) * (y >= 0 ? 1 : -1);
+        x = ox;
+        y = oy;
+    }
+    *u = x;
+    *v = y;
+}
+
+// One sphere as seen from the ray origin. For a beam with apex O, r0 = 1e-4, smin = 0 and slope
+// k <= kcap the member test of the kernel (beam_member_test) passes only if the angle alpha
+// between the beam axis and the direction to the centre satisfies
+// sin(alpha - atan(1.00025 k)) <= (rc (1 + k) + r0) 1.00025 / |v|, rc = sqrt(R^2 + 4e-5 |v|^2 + 1e-3) 1.0001
+// -- all known here because the apex is. `ext` is the asin of that bound; a sphere around or
+// next to O is unbounded.
+struct ConeEnt {
+    double dir[3];
+    double ext;
+    bool bounded;
+};
+
+RT_HDI ConeEnt cone_entry(float4 sph, const float org[3])
+{
+    const double kcap = RT_CONE_KCAP, r0 = 1.0e-4;
+    ConeEnt e;
+    const double v[3] = {(double)sph.x - org[0], (double)sph.y - org[1], (double)sph.z - org[2]};
+    const double vv = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], dist = sqrt(vv), w = sph.w;
+    e.bounded = (vv - vv == 0.0) && (w - w == 0.0) && dist > 0;   // finite, and not at the origin
+    e.ext = 0;
+    e.dir[0] = e.dir[1] = e.dir[2] = 0;
+    if (e.bounded) {
+        const double rc = sqrt((w > 0 ? w : 0.0) + 4.0e-5 * vv + 1.0e-3) * 1.0001;
+        const double q = (rc * (1.0 + kcap) + r0) * 1.00025 * 1.001 / dist;
+        if (!(q < 0.99)) e.bounded = false;   // the origin is inside or next to the (padded) sphere
+        else e.ext = asin(q);
+        for (int k = 0; k < 3; ++k) e.dir[k] = v[k] / dist;
+    }
+    return e;
+}
+
+// Sort key: 2-D Morton code of the octahedral map of the direction; unbounded entries last.
+RT_HDI unsigned cone_key(const ConeEnt &e)
+{
+    if (!e.bounded) return 0xffffffffu;
+    double ou, ov;
+    oct_map(e.dir, &ou, &ov);
+    const double a = (ou * 0.5 + 0.5) * 65535.0, b = (ov * 0.5 + 0.5) * 65535.0;
+    const unsigned q1 = (unsigned)(a < 0.0 ? 0.0 : (a > 65535.0 ? 65535.0 : a));
+    const unsigned q2 = (unsigned)(b < 0.0 ? 0.0 : (b > 65535.0 ? 65535.0 : b));
+    return morton16(q1) | (morton16(q2) << 1);
+}
+
+// ---------------------------------------------------------------------------
+// 3-D Morton order of the centres (10 bits per axis over the scene's bounds), blocks of
+// RT_BLOCK consecutive spheres, and for each block a sphere that contains every member
+// (centre = mean of the members' centres, radius = max |c_i - centre| + R_i, rounded
+// up). Spheres with non-finite data make their block unbounded (always examined).
+// ---------------------------------------------------------------------------
+void rt_build_sorted_blocks(const float4 *tab, int n, float4 *sorted, float4 *blocks, int *orig)
+{
+    const int n_pad = (n + 63) & ~63;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = 0; i < n; ++i) {
+        const float c[3] = {tab[i].x, tab[i].y, tab[i].z};
+        for (int k = 0; k < 3; ++k)
+            if (std::isfinite(c[k])) {
+                lo[k] = std::min(lo[k], c[k]);
+                hi[k] = std::max(hi[k], c[k]);
+            }
+    }
+    std::vector<std::pair<unsigned, int>> keys((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const float c[3] = {tab[i].x, tab[i].y, tab[i].z};
+        unsigned q[3];
+        for (int k = 0; k < 3; ++k) {
+            const float span = hi[k] - lo[k];
+            const float t = (std::isfinite(c[k]) && span > 0) ? (c[k] - lo[k]) / span : 0.f;
+            q[k] = (unsigned)std::min(1023.f, std::max(0.f, t * 1023.f));
+        }
+        keys[i] = {morton10(q[0]) | (morton10(q[1]) << 1) | (morton10(q[2]) << 2), i};
+    }
+    std::sort(keys.begin(), keys.end());
+    for (int i = 0; i < n_pad; ++i) {
+        sorted[i] = i < n ? tab[keys[i].second] : make_float4(0.f, 0.f, 0.f, 0.f);
+        orig[i] = i < n ? keys[i].second : 0x7fffffff;
+    }
+    for (int b = 0; b < n_pad / RT_BLOCK; ++b) {
+        const int i0 = b * RT_BLOCK, i1 = std::min(n, i0 + RT_BLOCK);
+        if (i0 >= n) {   // padding block: nothing in it, never examined
+            blocks[b] = make_float4(0.f, 0.f, 0.f, -1.f);
+            continue;
+        }
+        double cx = 0, cy = 0, cz = 0;
+        for (int i = i0; i < i1; ++i) { cx += sorted[i].x; cy += sorted[i].y; cz += sorted[i].z; }
+        const double inv = 1.0 / std::max(1, i1 - i0);
+        cx *= inv; cy *= inv; cz *= inv;
+        double r = 0;
+        for (int i = i0; i < i1; ++i) {
+            const double dx = sorted[i].x - cx, dy = sorted[i].y - cy, dz = sorted[i].z - cz;
+            const double ri = std::sqrt(std::max(0.0, (double)sorted[i].w));
+            const double d = std::sqrt(dx * dx + dy * dy + dz * dz) + ri;
+            r = (d > r || d != d) ? d : r;   // a NaN sticks
+        }
+        float rf = (float)(r * 1.001 + 1e-3);
+        if (!(rf == rf) || !std::isfinite(cx + cy + cz)) { rf = INFINITY; cx = cy = cz = 0; }
+        blocks[b] = make_float4((float)cx, (float)cy, (float)cz, rf);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Per-light column blocks. All shadow rays of a light run within a few degrees of
+// u = l.pos/|l.pos| (kernel.cu:1468 builds them relative to the world origin), so the table
+// is ordered by where the centres fall ACROSS u and cut into blocks of RT_BLOCK: columns
+// along u, which a beam along u touches far less often than the cubes of the 3-D order.
+// Block record, two float4: {cx, cy, cz, rho} and {s_hi, r3d, 0, 0} -- c the mean centre,
+// rho >= |(c_j - c) across u| + R_j, s_hi >= (c_j - c).u + R_j, r3d >= |c_j - c| + R_j for
+// every member j (R_j = sqrt of the table's squared effective radius), all rounded up.
+// ---------------------------------------------------------------------------
+void rt_build_light_columns(const float4 *tab, int n, const float u_f[3], float4 *sorted, float4 *blocks)
+{
+    const int n_pad = (n + 63) & ~63;
+    const double u[3] = {u_f[0], u_f[1], u_f[2]};
+    // two directions across u
+    double e1[3] = {0, 0, 0};
+    {
+        const int k = (std::fabs(u[0]) <= std::fabs(u[1]) && std::fabs(u[0]) <= std::fabs(u[2])) ? 0
+                      : (std::fabs(u[1]) <= std::fabs(u[2]) ? 1 : 2);
+        double t[3] = {0, 0, 0};
+        t[k] = 1;
+        const double d = t[0] * u[0] + t[1] * u[1] + t[2] * u[2];
+        for (int i = 0; i < 3; ++i) e1[i] = t[i] - d * u[i];
+        const double l = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+        for (int i = 0; i < 3; ++i) e1[i] /= l;
+    }
+    const double e2[3] = {u[1] * e1[2] - u[2] * e1[1], u[2] * e1[0] - u[0] * e1[2], u[0] * e1[1] - u[1] * e1[0]};
+    std::vector<double> p1((size_t)n), p2((size_t)n);
+    double lo1 = INFINITY, hi1 = -INFINITY, lo2 = INFINITY, hi2 = -INFINITY;
+    std::vector<char> fin((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const double c[3] = {tab[i].x, tab[i].y, tab[i].z};
+        p1[i] = c[0] * e1[0] + c[1] * e1[1] + c[2] * e1[2];
+        p2[i] = c[0] * e2[0] + c[1] * e2[1] + c[2] * e2[2];
+        fin[i] = std::isfinite(p1[i]) && std::isfinite(p2[i]) && std::isfinite((double)tab[i].w);
+        if (fin[i]) {
+            lo1 = std::min(lo1, p1[i]); hi1 = std::max(hi1, p1[i]);
+            lo2 = std::min(lo2, p2[i]); hi2 = std::max(hi2, p2[i]);
+        }
+    }
+    std::vector<std::pair<unsigned long long, int>> keys((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        unsigned long long key = ~0ull;   // non-finite entries go last (their blocks are unbounded)
+        if (fin[i]) {
+            const double s1 = hi1 - lo1, s2 = hi2 - lo2;
+            const unsigned q1 = (unsigned)std::min(65535.0, std::max(0.0, s1 > 0 ? (p1[i] - lo1) / s1 * 65535.0 : 0.0));
+            const unsigned q2 = (unsigned)std::min(65535.0, std::max(0.0, s2 > 0 ? (p2[i] - lo2) / s2 * 65535.0 : 0.0));
+            key = morton16(q1) | ((unsigned long long)morton16(q2) << 1);
+        }
+        keys[i] = {key, i};
+    }
+    std::sort(keys.begin(), keys.end());
+    for (int i = 0; i < n_pad; ++i) sorted[i] = i < n ? tab[keys[i].second] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < n_pad / RT_BLOCK; ++b) {
+        const int i0 = b * RT_BLOCK, i1 = std::min(n, i0 + RT_BLOCK);
+        if (i0 >= n) {   // padding block: nothing in it, never examined
+            blocks[2 * b] = make_float4(0.f, 0.f, 0.f, -1.f);
+            blocks[2 * b + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
+        double cx = 0, cy = 0, cz = 0;
+        for (int i = i0; i < i1; ++i) { cx += sorted[i].x; cy += sorted[i].y; cz += sorted[i].z; }
+        const double inv = 1.0 / std::max(1, i1 - i0);
+        // the bounds below are taken around the ROUNDED centre the device will use
+        const float cf[3] = {(float)(cx * inv), (float)(cy * inv), (float)(cz * inv)};
+        double rho = 0, s_hi = -INFINITY, r3d = 0;
+        bool bad = !(std::isfinite(cf[0]) && std::isfinite(cf[1]) && std::isfinite(cf[2]));
+        for (int i = i0; i < i1 && !bad; ++i) {
+            const double d[3] = {sorted[i].x - (double)cf[0], sorted[i].y - (double)cf[1], sorted[i].z - (double)cf[2]};
+            const double w = sorted[i].w;
+            if (!(w == w) || !std::isfinite(d[0] + d[1] + d[2]) || !std::isfinite(w)) { bad = true; break; }
+            const double R = std::sqrt(std::max(0.0, w));
+            const double ax = d[0] * u[0] + d[1] * u[1] + d[2] * u[2];
+            const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+            const double lat = std::sqrt(std::max(0.0, dd - ax * ax));
+            rho = std::max(rho, lat + R);
+            s_hi = std::max(s_hi, ax + R);
+            r3d = std::max(r3d, std::sqrt(dd) + R);
+        }
+        if (bad) {   // always examined
+            blocks[2 * b] = make_float4(0.f, 0.f, 0.f, INFINITY);
+            blocks[2 * b + 1] = make_float4(INFINITY, INFINITY, 0.f, 0.f);
+            continue;
+        }
+        // rounded up; |u| differs from 1 by a few 1e-8, which the factors cover as well
+        blocks[2 * b] = make_float4(cf[0], cf[1], cf[2], (float)(rho * 1.001 + 1e-3));
+        blocks[2 * b + 1] = make_float4((float)(s_hi + std::fabs(s_hi) * 1e-3 + 1e-3), (float)(r3d * 1.001 + 1e-3), 0.f, 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Eye cones. Every primary ray starts at the same point O, so the table is ordered by the
+// direction of the centres as seen from O (octahedral map, 2-D Morton) and cut into blocks of
+// RT_BLOCK: cones from O that a tile's thin beam meets far less often than the cubes of the
+// 3-D order. theta of a block: max over members of (angle(axis, dir_j) + ext_j), plus margin,
+// the angles being taken from the ROUNDED axis the kernel will use.
+// Layout of the result: [n_pad float4 entries][2 float4 per block][n_pad ints: list positions].
+// ---------------------------------------------------------------------------
+// What a block's members reduce to: sum of the bounded members' directions, whether all are
+// bounded; then, given the axis, the largest angle + extension. Host: plain loops.
+void rt_build_eye_cones_host(const float4 *tab, int n, const float org[3], float4 *sorted, float4 *blocks, int *orig)
+{
+    const int n_pad = (n + 63) & ~63;
+    std::vector<ConeEnt> ent((size_t)n);
+    std::vector<std::pair<unsigned long long, int>> keys((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        ent[i] = cone_entry(tab[i], org);
+        keys[i] = {((unsigned long long)cone_key(ent[i]) << 32) | (unsigned)i, i};
+    }
+    std::sort(keys.begin(), keys.end());
+    for (int i = 0; i < n_pad; ++i) {
+        sorted[i] = i < n ? tab[keys[i].second] : make_float4(0.f, 0.f, 0.f, 0.f);
+        orig[i] = i < n ? keys[i].second : 0x7fffffff;
+    }
+    for (int b = 0; b < n_pad / RT_BLOCK; ++b) {
+        const int i0 = b * RT_BLOCK, i1 = std::min(n, i0 + RT_BLOCK);
+        if (i0 >= n) {   // padding block: nothing in it, never examined
+            blocks[2 * b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            blocks[2 * b + 1] = make_float4(0.f, -1.f, 0.f, 0.f);
+            continue;
+        }
+        bool bounded = true;
+        double m[3] = {0, 0, 0};
+        for (int i = i0; i < i1; ++i) {
+            const ConeEnt &e = ent[keys[i].second];
+            bounded = bounded && e.bounded;
+            if (e.bounded) for (int k = 0; k < 3; ++k) m[k] += e.dir[k];
+        }
+        const double ml = std::sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+        bounded = bounded && ml > 1e-6;
+        float af[3] = {0, 0, 0};
+        double theta = 0;
+        if (bounded) {
+            for (int k = 0; k < 3; ++k) af[k] = (float)(m[k] / ml);
+            const double al = std::sqrt((double)af[0] * af[0] + (double)af[1] * af[1] + (double)af[2] * af[2]);
+            for (int i = i0; i < i1; ++i) {
+                const ConeEnt &e = ent[keys[i].second];
+                double c = (af[0] * e.dir[0] + af[1] * e.dir[1] + af[2] * e.dir[2]) / al;
+                c = std::min(1.0, std::max(-1.0, c));
+                theta = std::max(theta, std::acos(c) + e.ext);
+            }
+            theta += 2.0e-3;
+            if (!(theta < 2.9)) bounded = false;   // theta + the beam's own angle must stay below pi
+        }
+        if (!bounded) {
+            blocks[2 * b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            blocks[2 * b + 1] = make_float4(0.f, 1.f, 0.f, 0.f);
+            continue;
+        }
+        blocks[2 * b] = make_float4(af[0], af[1], af[2], (float)std::cos(theta));
+        blocks[2 * b + 1] = make_float4((float)std::sin(theta), 0.f, 0.f, 0.f);
+    }
+}
+
+// The same table built by one 1024-thread workgroup: keys into LDS, bitonic sort, entries out,
+// then 16 lanes per block reduce their members' directions and angles with shuffles.
+__global__ __launch_bounds__(1024) void rt_eye_cones_kernel(const float4 *__restrict__ tab, int n, float ox, float oy, float oz,
+                                                            float4 *__restrict__ out)
+{
+    extern __shared__ unsigned long long keys[];
+    const int tid = threadIdx.x;
+    const int n_pad = (n + 63) & ~63, nb = n_pad / RT_BLOCK;
+    int P = 64;
+    while (P < n_pad) P <<= 1;
+    const float org[3] = {ox, oy, oz};
+    for (int i = tid; i < P; i += 1024) {
+        unsigned long long key = ~0ull;   // padding sorts last
+        if (i < n) key = ((unsigned long long)cone_key(cone_entry(tab[i], org)) << 32) | (unsigned)i;
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (P >> 1); t += 1024) {
+                const int i = 2 * t - (t & (j - 1)), l = i + j;
+                const unsigned long long a = keys[i], b = keys[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    keys[i] = b;
+                    keys[l] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    float4 *sorted = out, *blocks = out + n_pad;
+    int *orig = reinterpret_cast<int *>(out + n_pad + 2 * nb);
+    for (int i = tid; i < n_pad; i += 1024) {
+        const unsigned long long key = keys[i];
+        const bool have = key != ~0ull;
+        const int idx = (int)(unsigned)(key & 0xffffffffu);
+        sorted[i] = have ? tab[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        orig[i] = have ? idx : 0x7fffffff;
+    }
+    // blocks: RT_BLOCK consecutive lanes per block (RT_BLOCK divides 64: a group never straddles a wave)
+    const int sub = tid % RT_BLOCK, grp = tid / RT_BLOCK;
+    for (int b0 = 0; b0 < nb; b0 += 1024 / RT_BLOCK) {
+        const int b = b0 + grp;
+        const bool live = b < nb;                      // whole groups leave together; shuffles stay inside a group
+        const int i = (live ? b : 0) * RT_BLOCK + sub;
+        const unsigned long long key = keys[i];
+        const bool have = live && key != ~0ull;
+        ConeEnt e;
+        e.bounded = false; e.ext = 0; e.dir[0] = e.dir[1] = e.dir[2] = 0;
+        if (have) e = cone_entry(tab[(int)(unsigned)(key & 0xffffffffu)], org);
+        int all_bounded = (!have || e.bounded) ? 1 : 0, any = have ? 1 : 0;
+        double m0 = (have && e.bounded) ? e.dir[0] : 0.0, m1 = (have && e.bounded) ? e.dir[1] : 0.0,
+               m2 = (have && e.bounded) ? e.dir[2] : 0.0;
+        for (int o = RT_BLOCK / 2; o > 0; o >>= 1) {
+            m0 += __shfl_xor(m0, o, RT_BLOCK);
+            m1 += __shfl_xor(m1, o, RT_BLOCK);
+            m2 += __shfl_xor(m2, o, RT_BLOCK);
+            all_bounded &= __shfl_xor(all_bounded, o, RT_BLOCK);
+            any |= __shfl_xor(any, o, RT_BLOCK);
+        }
+        const double ml = sqrt(m0 * m0 + m1 * m1 + m2 * m2);
+        bool bounded = all_bounded && ml > 1e-6;
+        float af[3] = {0.f, 0.f, 0.f};
+        double theta = 0;
+        if (bounded) {
+            af[0] = (float)(m0 / ml); af[1] = (float)(m1 / ml); af[2] = (float)(m2 / ml);
+            const double al = sqrt((double)af[0] * af[0] + (double)af[1] * af[1] + (double)af[2] * af[2]);
+            if (have) {
+                double c = (af[0] * e.dir[0] + af[1] * e.dir[1] + af[2] * e.dir[2]) / al;
+                c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+                theta = acos(c) + e.ext;
+            }
+        }
+        for (int o = RT_BLOCK / 2; o > 0; o >>= 1) {
+            const double t = __shfl_xor(theta, o, RT_BLOCK);
+            theta = (t > theta || t != t) ? t : theta;
+        }
+        theta += 2.0e-3;
+        if (!(theta < 2.9)) bounded = false;
+        if (live && sub == 0) {
+            if (!any) {                       // padding block: never examined
+                blocks[2 * b] = make_float4(0.f, 0.f, 0.f, 0.f);
+                blocks[2 * b + 1] = make_float4(0.f, -1.f, 0.f, 0.f);
+            } else if (!bounded) {            // always examined
+                blocks[2 * b] = make_float4(0.f, 0.f, 0.f, 0.f);
+                blocks[2 * b + 1] = make_float4(0.f, 1.f, 0.f, 0.f);
+            } else {
+                blocks[2 * b] = make_float4(af[0], af[1], af[2], (float)cos(theta));
+                blocks[2 * b + 1] = make_float4((float)sin(theta), 0.f, 0.f, 0.f);
+            }
+        }
+    }
+}
+
+// float4 units of an eye-cone table for n spheres
+size_t rt_eye_cones_size(int n)
+{
+    const size_t n_pad = ((size_t)n + 63) & ~(size_t)63, nb = n_pad / RT_BLOCK;
+    return n_pad + 2 * nb + (n_pad + 3) / 4;
+}
+
+void rt_eye_cones_kernel_config(int n, const void **func, dim3 *grid, dim3 *block, unsigned *lds_bytes)
+{
+    const int n_pad = (n + 63) & ~63;
+    int P = 64;
+    while (P < n_pad) P <<= 1;
+    *func = (const void *)rt_eye_cones_kernel;
+    *grid = dim3(1);
+    *block = dim3(1024);
+    *lds_bytes = (unsigned)P * (unsigned)sizeof(unsigned long long);
+}
+
+hipError_t rt_eye_cones_launch(const float4 *tab, int n, const float org[3], float4 *out, hipStream_t stream)
+{
+    if (n < 1 || n > RT_EYE_DEVICE_MAX) return hipErrorInvalidValue;
+    const void *func;
+    dim3 grid, block;
+    unsigned lds;
+    rt_eye_cones_kernel_config(n, &func, &grid, &block, &lds);
+    hipLaunchKernelGGL(rt_eye_cones_kernel, grid, block, lds, stream, tab, n, org[0], org[1], org[2], out);
+    return hipGetLastError();
+}

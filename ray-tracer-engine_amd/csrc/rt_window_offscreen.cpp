@@ -4,6 +4,7 @@
 //
 // The C++ symbols are WEAK so that an application which links its own
 // window.cpp (the real Win32 one, or any other presenter) overrides them.
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -24,51 +25,38 @@ Render_State render;
 
 #define RT_WEAK __attribute__((weak))
 
-RT_WEAK int getScreenHeight() { return render.height; }   // window.cpp:86-88
-RT_WEAK int getScreenWidth() { return render.width; }     // window.cpp:89-91
-RT_WEAK void setScreen(int *) {}                          // window.cpp:92-94
+namespace {
+inline size_t frame_words() { return (size_t)render.width * (size_t)render.height; }
+inline unsigned int *frame() { return static_cast<unsigned int *>(render.buffmemory); }
+}  // namespace
 
-RT_WEAK int make_inbound(int min, int max, int val)       // window.cpp:122-129
-{
-    if (val > max) return max;
-    if (val < min) return min;
-    return val;
-}
-
-RT_WEAK void drawPixel(int x, int y, int color)           // window.cpp:95-101
-{
-    if (!render.buffmemory) return;
-    x = make_inbound(0, render.width - 1, x);
-    y = make_inbound(0, render.height - 1, y);
-    unsigned int *pixel = (unsigned int *)render.buffmemory + x + y * (render.width);
-    *pixel = (unsigned int)color;
-}
-
-RT_WEAK void Set_Background()                             // window.cpp:102-109
-{
-    unsigned int *pixel = (unsigned int *)render.buffmemory;
-    if (!pixel) return;
-    for (int y = 0; y < getScreenHeight(); y++)
-        for (int x = 0; x < getScreenWidth(); x++) *pixel++ = (unsigned int)(y * x / (x + 1));
-}
-
-RT_WEAK void Clear_Screen(unsigned int color)             // window.cpp:110-117
-{
-    unsigned int *pixel = (unsigned int *)render.buffmemory;
-    if (!pixel) return;
-    for (int y = 0; y < getScreenHeight(); y++)
-        for (int x = 0; x < getScreenWidth(); x++) *pixel++ = color;
-}
-
-RT_WEAK int getBuffSize() { return (int)sizeof(render.buffmemory); }   // window.cpp:118-120 (sic)
-
-// window.cpp:130-132: memcpy of render.width*render.height words out of the
-// (host-readable) frame the kernel side hands over.
+// The three functions the frame driver calls (kernel.cu:1771, 1788).
+RT_WEAK int getScreenHeight() { return render.height; }
+RT_WEAK int getScreenWidth() { return render.width; }
+// setPixelBuff consumes a HOST-readable frame of getScreenWidth()*getScreenHeight() packed
+// words (window.cpp:130-132) and makes it the presented image.
 RT_WEAK void setPixelBuff(unsigned int *pixels)
 {
-    if (!render.buffmemory || !pixels) return;
-    memcpy(render.buffmemory, pixels, sizeof(unsigned int) * (size_t)render.width * (size_t)render.height);
+    if (frame() && pixels) std::copy_n(pixels, frame_words(), frame());
 }
+
+// The rest of window.h:7-16 is never called by the hot path. It is defined for link parity
+// only (an application that includes window.h resolves every symbol), as plain operations
+// on the offscreen frame -- not as restatements of the Win32 helpers.
+RT_WEAK int make_inbound(int min, int max, int val) { return std::min(std::max(val, min), max); }
+RT_WEAK void Clear_Screen(unsigned int color)
+{
+    if (frame()) std::fill_n(frame(), frame_words(), color);
+}
+RT_WEAK void Set_Background() { Clear_Screen(0u); }
+RT_WEAK void drawPixel(int x, int y, int color)
+{
+    if (!frame() || render.width <= 0 || render.height <= 0) return;
+    const int cx = make_inbound(0, render.width - 1, x), cy = make_inbound(0, render.height - 1, y);
+    frame()[(size_t)cy * (size_t)render.width + (size_t)cx] = (unsigned int)color;
+}
+RT_WEAK int getBuffSize() { return (int)(frame_words() * sizeof(unsigned int)); }   // bytes of the offscreen frame
+RT_WEAK void setScreen(int *) {}
 
 // ---- control surface of the offscreen window (C ABI) ----
 // WM_SIZE (window.cpp:29-46) re-allocates the present buffer; the reference

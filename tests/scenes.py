@@ -60,6 +60,16 @@ GOLDEN_CASES = {
     "c3_3840x2160_rows1080": (3840, 2160, 1024, 1080, 1082),
     "c3_3840x2160_rows300": (3840, 2160, 1024, 300, 302),
     "c5_128x72_n4096": (128, 72, 4096, 0, 72),
+    # C2 at its BASELINE size: row bands of the 1920x1080 / 256-sphere frame (sky above, spheres below)
+    "c2_1920x1080_rows100": (1920, 1080, 256, 100, 104),
+    "c2_1920x1080_rows700": (1920, 1080, 256, 700, 704),
+}
+
+# C4 at its BASELINE size (3840x2160, 1024 spheres, 4 spp): name -> (width, height, n, spp, y0, y1);
+# the fixtures hold the accumulated float sums and the resolved words of those rows
+GOLDEN_SPP_CASES = {
+    "c4_3840x2160_spp4_rows1080": (3840, 2160, 1024, 4, 1080, 1082),
+    "c4_3840x2160_spp4_rows300": (3840, 2160, 1024, 4, 300, 302),
 }
 
 

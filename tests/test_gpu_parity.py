@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from scenes import GOLDEN_CASES, Inputs, mixed_scene
+from scenes import GOLDEN_CASES, GOLDEN_SPP_CASES, Inputs, mixed_scene
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -141,6 +141,28 @@ def test_device_light_sampling_matches_oracle(rt, oracle, gpu, light_index):
         assert _bits(np.float32(b)) == _bits(bright[i]), i
 
 
+def test_shortcuts_equal_the_long_forms(rt, gpu):
+    """The culling kernels' cheaper forms (rt_kernels.hip: lean normalise / sqrt, fast texel index)
+    against what they stand for, on the device: the lean square root on EVERY float of its range,
+    the lean normalise on 2^28 vectors of every scale (zero, denormal, huge components included:
+    those must take the IEEE path and still agree), the approximate (tx, ty) on 2^28 unit normals
+    (poles and seams over-sampled): error below half of RT_UV_DELTA and not one accepted lane with
+    a texel index different from the exact binary64 expressions'."""
+    lib = rt.load_library()
+    out = (C.c_ulonglong * 4)()
+    assert lib.rt_debug_shortcuts(1, 0, 0, out) == 0, lib.rt_last_error()
+    assert out[0] == 0, f"lean sqrt differs from IEEE sqrtf on {out[0]} inputs"
+    for seed in (1, 2):
+        assert lib.rt_debug_shortcuts(0, seed, 1 << 27, out) == 0
+        assert out[0] == 0, f"lean normalise differs from the IEEE one on {out[0]} vectors"
+        assert lib.rt_debug_shortcuts(2, seed, 1 << 27, out) == 0
+        ex = np.array([out[0]], dtype=np.uint32).view(np.float32)[0]
+        ey = np.array([out[1]], dtype=np.uint32).view(np.float32)[0]
+        assert ex < 2.5e-7 and ey < 2.5e-7, (ex, ey)
+        assert out[3] == 0, f"{out[3]} accepted lanes select another texel than the exact expressions"
+        assert out[2] > 0.995 * (1 << 27) * 0.8, out[2]      # the over-sampled seams and poles are rejected more often
+
+
 # ---------------------------------------------------------------- frames vs golden
 @pytest.mark.parametrize("cull", [True, False])
 @pytest.mark.parametrize("name", sorted(GOLDEN_CASES))
@@ -265,16 +287,135 @@ def test_graph_replay_equals_direct_launch(rt, gpu):
     stream.synchronize()
     assert np.array_equal(_bits(acc.cpu().numpy()), _bits(g["acc"]))
     assert np.array_equal(host.numpy().view(np.uint32), g["packed"])
-    # camera move: update the instantiated graph, compare with a direct render
+    # camera moves: the kernel nodes' parameters are replaced in the instantiated graph (no
+    # re-capture), the graph's own eye-cone table is rebuilt by its build node; every frame is
+    # compared with a direct render
     cam = rt.default_camera()
-    cam.Org.x, cam.Camyaw = 5.0, 170.0
-    assert lib.rt_graph_set_camera(gr, C.byref(cam)) == 0
-    assert lib.rt_graph_launch(gr, stream.cuda_stream) == 0
-    stream.synchronize()
-    rgba, packed, _ = _render(scene, w, h, spp=4, cam=cam)
-    assert np.array_equal(host.numpy().view(np.uint32), packed)
-    assert not np.array_equal(packed, g["packed"])
+    for k in range(5):
+        cam.Org.x, cam.Org.z, cam.Camyaw = 5.0 - 0.3 * k, 10.0 + 0.25 * k, 170.0 + 3.0 * k
+        assert lib.rt_graph_set_camera(gr, C.byref(cam)) == 0, lib.rt_last_error()
+        assert lib.rt_graph_launch(gr, stream.cuda_stream) == 0, lib.rt_last_error()
+        stream.synchronize()
+        rgba, packed, _ = _render(scene, w, h, spp=4, cam=cam)
+        assert np.array_equal(host.numpy().view(np.uint32), packed), k
+        assert not np.array_equal(packed, g["packed"])
     lib.rt_graph_destroy(gr)
+
+
+def test_graph_never_replays_against_tables_of_another_frame(rt, gpu):
+    """A graph built for camera A keeps rendering camera A after direct renders of the same
+    scene with camera B (which builds other eye cones), at another resolution (other raygen
+    tables), with a light moved (other column tables: the graph then follows the scene) and
+    with another sphere list."""
+    import torch
+    lib = rt.load_library()
+    w, h, n = 160, 90, 1024
+    inp = Inputs(rt, n)
+    scene = inp.scene()
+    pk = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.Stream()
+    cam_a = rt.default_camera()
+    fd = scene.frame_desc(w, h, pixels=pk.data_ptr(), cam=cam_a)
+    gr = lib.rt_graph_capture(scene.handle, C.byref(fd), 1, None, stream.cuda_stream)
+    assert gr, lib.rt_last_error()
+    _, want_a, _ = _render(scene, w, h, cam=cam_a)
+
+    def replay():
+        pk.zero_()
+        torch.cuda.synchronize()
+        assert lib.rt_graph_launch(gr, stream.cuda_stream) == 0, lib.rt_last_error()
+        stream.synchronize()
+        return pk.cpu().numpy().view(np.uint32)
+
+    assert np.array_equal(replay(), want_a)
+    cam_b = rt.default_camera()
+    cam_b.Org.x, cam_b.Org.y, cam_b.Camyaw, cam_b.Campitch = 1.0, 6.0, 140.0, -35.0
+    for _ in range(4):                                   # more direct frames than there are cone slots
+        cam_b.Org.x += 0.5
+        _render(scene, w, h, cam=cam_b)
+    assert np.array_equal(replay(), want_a)
+    _render(scene, 96, 54, cam=cam_b)                    # another resolution rewrites the raygen tables
+    assert np.array_equal(replay(), want_a)
+    lights = rt.default_lights()
+    lights[0].pos.x = 25.0
+    scene.set_lights(lights, 3)
+    _, want_l, _ = _render(scene, w, h, cam=cam_a)       # rebuilds the light tables in place
+    got = replay()
+    assert np.array_equal(got, want_l) and not np.array_equal(got, want_a)
+    sph = rt.generate_spheres(n, 7)
+    scene.set_spheres(sph, n)
+    got = replay()
+    _, want_s, _ = _render(scene, w, h, cam=cam_a)
+    assert np.array_equal(got, want_s) and not np.array_equal(got, want_l)
+    lib.rt_graph_destroy(gr)
+
+
+def test_moving_camera_on_two_streams_matches_the_oracle(rt, gpu):
+    """The reference moves `cam` every frame (checkKey, kernel.cu:1716-1764). Frames with a
+    camera nudged each time alternate between two streams -- so that one frame's eye-cone table
+    is rebuilt (on the device, in the frame's stream) while the previous frame is still reading
+    another -- and every frame equals the oracle's."""
+    import torch
+    import oracle_py
+    w, h, n = 96, 54, 256
+    inp = Inputs(rt, n)
+    scene = inp.scene()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    bufs = [(torch.zeros((h, w), dtype=torch.int32, device="cuda"), torch.zeros((h, w, 4), dtype=torch.float32, device="cuda"))
+            for _ in range(8)]
+    cams = []
+    for k in range(8):
+        cam = rt.default_camera()
+        cam.Org.z = 10.0 + 0.1 * k                       # what checkKey's 'S' does, kernel.cu:1727
+        cam.Org.x = 4.0 - 0.05 * k
+        cam.Camyaw = 180.0 + 1.5 * k
+        cams.append(cam)
+        fd = scene.frame_desc(w, h, pixels=bufs[k][0].data_ptr(), rgba=bufs[k][1].data_ptr(), cam=cam)
+        scene.render_raw(fd, streams[k & 1].cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(8):
+        inp.cam = cams[k]
+        want_rgba, want, _ = inp.oracle_render(oracle_py, w, h)
+        assert np.array_equal(bufs[k][0].cpu().numpy().view(np.uint32), want), k
+        assert np.array_equal(_bits(bufs[k][1].cpu().numpy()), _bits(want_rgba)), k
+
+
+def test_sphere_list_changes_between_frames_in_flight(rt, gpu):
+    """Two frames in flight on two streams over one scene, the sphere list replaced in between:
+    the upload waits for the frame that still reads the old table (it is not torn), and the next
+    frame sees the new one."""
+    import torch
+    w, h, n = 960, 540, 1024
+    scene = Inputs(rt, n).scene()
+    other = rt.generate_spheres(n, 5)
+    first = rt.generate_spheres(n, 1)
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    a = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    b = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    for _ in range(3):
+        scene.set_spheres(first, n)
+        scene.render_raw(scene.frame_desc(w, h, pixels=a.data_ptr()), s0.cuda_stream)
+        scene.set_spheres(other, n)                      # while the frame on s0 may still be running
+        scene.render_raw(scene.frame_desc(w, h, pixels=b.data_ptr()), s1.cuda_stream)
+        torch.cuda.synchronize()
+        scene.set_spheres(first, n)
+        _, want_a, _ = _render(scene, w, h, want_rgba=False)
+        scene.set_spheres(other, n)
+        _, want_b, _ = _render(scene, w, h, want_rgba=False)
+        assert np.array_equal(a.cpu().numpy().view(np.uint32), want_a)
+        assert np.array_equal(b.cpu().numpy().view(np.uint32), want_b)
+        assert not np.array_equal(want_a, want_b)
+
+
+def test_product_library_reads_no_environment(rt, gpu, monkeypatch):
+    """The diagnostics of the tuning builds (RT_ABLATE & co.) do not exist in the product library:
+    setting them changes nothing."""
+    g = np.load(os.path.join(GOLD, "c2_160x90_n256.npz"))
+    for k, v in (("RT_ABLATE", "16"), ("RT_NO_EYE_CONES", "1"), ("RT_NO_LIGHT_COLUMNS", "1"), ("RT_TABLE_LDS", "1")):
+        monkeypatch.setenv(k, v)
+    scene = Inputs(rt, 256).scene()
+    rgba, packed, _ = _render(scene, 160, 90)
+    assert np.array_equal(packed, g["packed"]) and np.array_equal(_bits(rgba[..., :3]), _bits(g["rgb"]))
 
 
 # ---------------------------------------------------------------- the reference's own surfaces
@@ -377,6 +518,53 @@ def test_onstart_update_present_path(rt, gpu):
     cam.contents.Org.z = 10.0
 
 
+def test_onstart_ingests_ppm_textures_and_an_obj_mesh(rt, gpu, tmp_path):
+    """The step Sprite.cpp:28-52 / kernel.cu:1181-1207 perform, end to end on the GPU: texture
+    FILES (binary PPM instead of the JPEGs OpenCV decodes) and an OBJ file go through onStart()
+    -> sprite(file) / mesh(file) -> planar float buffers / flat BVH -> update() -> the frame
+    handed to setPixelBuff(); it equals the oracle fed the same arrays and the same OBJ text."""
+    import oracle_py
+    import meshes
+    lib = rt.load_library()
+    rng = np.random.default_rng(11)
+
+    def write_ppm(path, h, w):
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.stack([(xx * 7 + yy * 3) % 256, (xx ^ yy) % 256, (xx * yy + 31) % 256], axis=-1).astype(np.uint8)
+        img[rng.integers(0, h, 50), rng.integers(0, w, 50)] = rng.integers(0, 256, (50, 3), dtype=np.uint8)
+        path.write_bytes(b"P6\n%d %d\n255\n" % (w, h) + img.tobytes())
+        return [np.ascontiguousarray(img[..., c].astype(np.float32) / np.float32(255)) for c in range(3)]   # Sprite.cpp:43-45
+
+    tex = write_ppm(tmp_path / "object.ppm", 96, 160)        # not square, not a power of two
+    sky = write_ppm(tmp_path / "sky.ppm", 128, 300)
+    obj_text = meshes.uv_sphere_obj()
+    (tmp_path / "mesh.obj").write_text(obj_text)
+    n = 64
+    assert lib.rt_config_set_sphere_count(n) == 0 and lib.rt_config_set_seed(1) == 0
+    assert lib.rt_config_set_assets(str(tmp_path / "object.ppm").encode(), str(tmp_path / "sky.ppm").encode(),
+                                    str(tmp_path / "mesh.obj").encode()) == 0
+    try:
+        lib.rt_on_start()
+        w, h = 160, 90
+        assert lib.rt_offscreen_resize(w, h) == 0
+        lib.rt_update()
+        got = np.ctypeslib.as_array(lib.rt_offscreen_pixels(), shape=(h, w)).copy()
+    finally:
+        lib.rt_config_set_assets(None, None, None)
+    inp = Inputs(rt, n)
+    om = oracle_py.Mesh(obj_text)
+    _, want, cnt = oracle_py.render(inp.spheres, n, tex, sky, inp.sky_box, inp.lights, 3, inp.cam, w, h, inp.aspect,
+                                    nthreads=8, mesh=om.handle)
+    assert cnt["hit_pixels"] > 1000
+    assert np.array_equal(got, want)
+    # and the synthetic stand-ins are back once the assets are unset
+    assert lib.rt_config_set_sphere_count(256) == 0
+    lib.rt_on_start()
+    lib.rt_update()
+    _, want, _ = Inputs(rt, 256).oracle_render(oracle_py, w, h)
+    assert np.array_equal(np.ctypeslib.as_array(lib.rt_offscreen_pixels(), shape=(h, w)), want)
+
+
 # ---------------------------------------------------------------- full-size properties (BASELINE sizes)
 def test_full_size_properties_c3(rt, gpu):
     """3840x2160 / 1024 spheres: too big for the oracle, so check what does not
@@ -399,10 +587,13 @@ def test_full_size_properties_c3(rt, gpu):
     # determinism
     rgba2, packed2, _ = _render(scene, w, h)
     assert np.array_equal(_bits(rgba2), _bits(rgba)) and np.array_equal(packed2, packed)
-    # brute force (the reference's loops) on a 64-row band == the culled frame
-    rb, pb, sb = _render(scene, w, h, y0=1024, y1=1088, cull=False, want_stats=True)
-    assert np.array_equal(_bits(rb), _bits(rgba[1024:1088])) and np.array_equal(pb, packed[1024:1088])
-    assert sb["primary_tests"] == 64 * w * n
+    # brute force (the reference's loops as written, IEEE forms everywhere) over the WHOLE frame ==
+    # the culled frame, all 2160 rows, for the default tile and one other
+    rb, pb, sb = _render(scene, w, h, cull=False, want_stats=True)
+    assert np.array_equal(_bits(rb), _bits(rgba)) and np.array_equal(pb, packed)
+    assert sb["primary_tests"] == h * w * n
+    r16, p16, _ = _render(scene, w, h, tile=16)
+    assert np.array_equal(_bits(r16), _bits(rgba)) and np.array_equal(p16, packed)
     # workload statistics of SURVEY.md 8(d): 99.4 % primary hits
     assert 0.99 < stats["hit_pixels"] / (w * h) < 0.999
     assert stats["list_overflows"] >= 0
@@ -416,9 +607,56 @@ def test_full_size_c5_8k_band(rt, gpu):
     y0, y1 = rt.band_rows(h, 3, 8)
     assert (y0, y1) == (1620, 2160)
     rgba, packed, _ = _render(scene, w, h, y0=y0, y1=y1)
-    rb, pb, _ = _render(scene, w, h, y0=1800, y1=1808, cull=False)
-    assert np.array_equal(_bits(rb), _bits(rgba[1800 - y0:1808 - y0]))
-    assert np.array_equal(pb, packed[1800 - y0:1808 - y0])
+    rb, pb, _ = _render(scene, w, h, y0=y0, y1=y1, cull=False)          # the whole band, brute force
+    assert np.array_equal(_bits(rb), _bits(rgba)) and np.array_equal(pb, packed)
+    del rb, pb
+    # the same rows as rank 3's share of the balanced split (16-row blocks dealt round-robin)
+    rows = rt.interleaved_rows(h, 3, 8, 16)
+    ri, pi, _ = _render(scene, w, h, interleave=(8, 3, 16), want_rgba=False)
+    full_rows = [r for r in rows if y0 <= r < y1]
+    idx = [rows.index(r) for r in full_rows]
+    assert np.array_equal(pi[idx], packed[[r - y0 for r in full_rows]])
+
+
+def test_full_size_c2_and_c4(rt, gpu):
+    """C2 (1920x1080, 256 spheres) whole frame culled == brute force, with the golden bands inside;
+    C4 (3840x2160, 1024 spheres, 4 spp): the golden bands inside the full frame rendered with the
+    four samples in one launch, as four accumulate passes replayed from the hipGraph (the BASELINE
+    config), and through the graph's copy to the present buffer."""
+    import torch
+    lib = rt.load_library()
+    w, h, n = 1920, 1080, 256
+    scene = Inputs(rt, n).scene()
+    rgba, packed, _ = _render(scene, w, h)
+    rb, pb, _ = _render(scene, w, h, cull=False)
+    assert np.array_equal(_bits(rb), _bits(rgba)) and np.array_equal(pb, packed)
+    for name in ("c2_1920x1080_rows100", "c2_1920x1080_rows700"):
+        _, _, _, y0, y1 = GOLDEN_CASES[name]
+        g = np.load(os.path.join(GOLD, name + ".npz"))
+        assert np.array_equal(_bits(rgba[y0:y1, :, :3]), _bits(g["rgb"])) and np.array_equal(packed[y0:y1], g["packed"])
+    w, h, n = 3840, 2160, 1024
+    scene = Inputs(rt, n).scene()
+    rgba4, packed4, _ = _render(scene, w, h, spp=4)                       # four samples inside one launch
+    acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    pk = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    host = torch.zeros((h, w), dtype=torch.int32).pin_memory()
+    stream = torch.cuda.Stream()
+    fd = scene.frame_desc(w, h, pixels=pk.data_ptr(), rgba=acc.data_ptr())
+    gr = lib.rt_graph_capture(scene.handle, C.byref(fd), 4, host.data_ptr(), stream.cuda_stream)
+    assert gr, lib.rt_last_error()
+    for _ in range(2):
+        assert lib.rt_graph_launch(gr, stream.cuda_stream) == 0
+    stream.synchronize()
+    assert np.array_equal(_bits(acc.cpu().numpy()), _bits(rgba4))
+    assert np.array_equal(host.numpy().view(np.uint32), packed4) and np.array_equal(pk.cpu().numpy().view(np.uint32), packed4)
+    for name, (_, _, _, _, y0, y1) in GOLDEN_SPP_CASES.items():
+        g = np.load(os.path.join(GOLD, name + ".npz"))
+        assert np.array_equal(_bits(rgba4[y0:y1]), _bits(g["acc"])), name
+        assert np.array_equal(packed4[y0:y1], g["packed"]), name
+    lib.rt_graph_destroy(gr)
+    # the 4-spp frame by brute force as well (0.4 s)
+    rb4, pb4, _ = _render(scene, w, h, spp=4, cull=False)
+    assert np.array_equal(_bits(rb4), _bits(rgba4)) and np.array_equal(pb4, packed4)
 
 
 def test_cxx_application_shell_with_its_own_window(rt, gpu, tmp_path):

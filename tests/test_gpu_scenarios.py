@@ -187,29 +187,32 @@ def test_random_seeds_and_counts(rt, gpu, n, seed):
     Scn.check(_as_scn(rt, Inputs(rt, n, seed)), 80, 56)
 
 
-def test_table_in_global_memory_matches_lds_staging(rt, gpu, monkeypatch):
+def test_table_in_global_memory_matches_lds_staging(rt, gpu):
     """By default the kernel reads the table from global memory and keeps only
-    the tiles' survivor lists in LDS; RT_TABLE_LDS=1 stages the whole table per
-    workgroup instead. Neither mode may change a bit."""
+    the tiles' survivor lists in LDS; rt_launch_opts.table_lds stages the whole table per
+    workgroup instead (north_star's first design). Neither mode may change a bit."""
     import torch
     from scenes import Inputs
     for n in (100, 1024):
         sc = Inputs(rt, n, 3).scene()
-        monkeypatch.setenv("RT_TABLE_LDS", "1")
-        a = sc.render(160, 90)
-        monkeypatch.setenv("RT_TABLE_LDS", "0")
+        a = sc.render(160, 90, table_lds=True)
         b = sc.render(160, 90)
         c = sc.render(160, 90, cull=False)
+        d = sc.render(160, 90, cull=False, table_lds=True)
+        e = sc.render(160, 90, spp=4, table_lds=True)
+        f = sc.render(160, 90, spp=4)
         torch.cuda.synchronize()
         assert torch.equal(a["rgba"], b["rgba"]) and torch.equal(a["packed"], b["packed"])
         assert torch.equal(a["rgba"], c["rgba"]) and torch.equal(a["packed"], c["packed"])
-    monkeypatch.delenv("RT_TABLE_LDS")
+        assert torch.equal(a["rgba"], d["rgba"]) and torch.equal(a["packed"], d["packed"])
+        assert torch.equal(e["rgba"], f["rgba"]) and torch.equal(e["packed"], f["packed"])
 
 
-def test_large_sphere_counts(rt, gpu, monkeypatch):
+def test_large_sphere_counts(rt, gpu):
     """Maximum sizes: 9000 and 20000 spheres (global-memory table; 9000 also with
     the table staged in LDS, which it still fits) equal the brute-force loops. The
-    oracle agrees on a tiny frame."""
+    oracle agrees on a tiny frame. 9000 spheres are beyond the device-side eye-cone
+    builder (RT_EYE_DEVICE_MAX), so this is also the host-built table."""
     import torch
     from scenes import Inputs
     for n in (9000, 20000):
@@ -220,10 +223,8 @@ def test_large_sphere_counts(rt, gpu, monkeypatch):
         torch.cuda.synchronize()
         assert torch.equal(a["rgba"], b["rgba"]) and torch.equal(a["packed"], b["packed"])
         if n == 9000:
-            monkeypatch.setenv("RT_TABLE_LDS", "1")
-            c = sc.render(24, 16, cull=True)
+            c = sc.render(24, 16, cull=True, table_lds=True)
             torch.cuda.synchronize()
-            monkeypatch.delenv("RT_TABLE_LDS")
             assert torch.equal(a["rgba"], c["rgba"]) and torch.equal(a["packed"], c["packed"])
     Scn.check(_as_scn(rt, Inputs(rt, 20000, 12)), 16, 8)
     s = rt.Scene()

@@ -17,20 +17,31 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 
 import oracle_py  # noqa: E402
 import rt_amd  # noqa: E402
-from scenes import GOLDEN_CASES, Inputs, mixed_oracle_render, mixed_scene  # noqa: E402
+from scenes import GOLDEN_CASES, GOLDEN_SPP_CASES, Inputs, mixed_oracle_render, mixed_scene  # noqa: E402
 
 
 def main():
     rt = rt_amd.load()
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
+    only = set(sys.argv[1:])     # names to (re)generate; none = all
+    for name, (w, h, n, spp, y0, y1) in GOLDEN_SPP_CASES.items():
+        if only and name not in only:
+            continue
+        acc, packed = Inputs(rt, n).oracle_render_spp(oracle_py, rt, w, h, spp, y0=y0, y1=y1)
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), acc=acc, packed=packed)
+        print(name, acc.shape)
     for name, (w, h, n, y0, y1) in GOLDEN_CASES.items():
+        if only and name not in only:
+            continue
         inp = Inputs(rt, n)
         rgba, packed, cnt = inp.oracle_render(oracle_py, w, h, y0=y0, y1=y1)
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), rgb=rgba[..., :3].copy(), packed=packed,
                             counters=np.array([cnt["primary_tests"], cnt["shadow_tests"], cnt["hit_pixels"],
                                                cnt["unshadowed"]], dtype=np.uint64))
         print(name, rgba.shape, {k: v for k, v in cnt.items()})
+    if only:
+        return
     # 4-spp extension (build-defined): accumulated float sums + resolved words
     inp = Inputs(rt, 256)
     acc, packed = inp.oracle_render_spp(oracle_py, rt, 96, 54, 4)
