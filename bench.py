@@ -43,6 +43,7 @@ import rt_amd  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak fp32 vector
 FLOP_PER_TEST = 17           # the 17-flop discriminant
+EV_EVERY = 4                 # launches between two event-timed ones in the timed loop
 
 
 def parse():
@@ -247,11 +248,12 @@ def main():
             if world > 1:
                 finish(b, streams)             # buffer set b is free again
             with torch.cuda.stream(streams[b]):
-                if i is not None and ev is not None:
-                    ev[i][0].record(streams[b])
+                timed = i is not None and ev is not None and i % EV_EVERY == 0
+                if timed:
+                    ev[i // EV_EVERY][0].record(streams[b])
                 scene.render_raw(fd_of(k, b), streams[b].cuda_stream)
-                if i is not None and ev is not None:
-                    ev[i][1].record(streams[b])
+                if timed:
+                    ev[i // EV_EVERY][1].record(streams[b])
                 if world > 1:                  # the frame's single collective, asynchronous, ordered after b's kernel
                     src = send2[b] if coll_dev == "cuda" else send2[b].cpu()
                     if rank == 0:
@@ -278,7 +280,10 @@ def main():
 
     # ---------------- the timed loop the contract asks for ----------------
     streams = two_streams if nfl == 2 else [main_stream, main_stream]
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events around every EV_EVERY-th launch of the timed loop (a pair of event records costs the
+    # loop ~15 us of stream time, 3 % of a frame: sampling keeps the timed region honest)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range((args.steps + EV_EVERY - 1) // EV_EVERY)]
     elapsed, k = timed_loop(make_step(streams, ev, lambda k, b: fds[b]), args.steps, args.warmup, make_sync(streams), world)
     packed = packed2[(k - 1) & 1]
     rgba = rgba2[(k - 1) & 1]
@@ -290,19 +295,25 @@ def main():
     if not args.no_extras:
         # camera nudged every frame (kernel.cu:1727 `cam.Org.z += 0.1`, back and forth so the view stays
         # the workload's): the eye-cone table is rebuilt on the device for every frame
-        def cam_of(k):
+        def cam_at(j):                 # eight positions 0.1 apart, walked back and forth
             cam = rt.default_camera()
-            cam.Org.z = 10.0 + 0.1 * ((k % 8) - 4 if (k // 8) % 2 == 0 else 4 - (k % 8))
+            cam.Org.z = 10.0 + 0.1 * (j - 4)
             return cam
+
+        def cam_of(k):
+            return cam_at(k % 8 if (k // 8) % 2 == 0 else 7 - (k % 8))
         s1 = [main_stream, main_stream]
         e_mv, _ = timed_loop(make_step(s1, None, lambda k, b: make_fd(b, cam_of(k))), args.steps, args.warmup, make_sync(s1), world)
-        e_st, _ = timed_loop(make_step(s1, None, lambda k, b: fds[b]), args.steps, args.warmup, make_sync(s1), world)
+        # the same positions, each held for an eighth of the loop: the same pixels to render, 8 table builds in all
+        hold = max(1, (args.steps + args.warmup + 7) // 8)
+        e_st, _ = timed_loop(make_step(s1, None, lambda k, b: make_fd(b, cam_at((k // hold) % 8))), args.steps, args.warmup,
+                             make_sync(s1), world)
         e_pl, _ = timed_loop(make_step(two_streams, None, lambda k, b: fds[b]), args.steps, args.warmup, make_sync(two_streams), world)
         e_mv, e_st, e_pl = reduce_max(e_mv, e_st, e_pl)
         rays = w * h * args.spp
         extras["moving_camera"] = {"ms_per_step": e_mv / args.steps * 1e3, "Mrays_per_s": rays / (e_mv / args.steps) / 1e6,
-                                   "static_camera_same_loop_ms": e_st / args.steps * 1e3,
-                                   "overhead_vs_static": e_mv / e_st - 1.0,
+                                   "same_positions_held_ms": e_st / args.steps * 1e3,
+                                   "overhead_vs_held": e_mv / e_st - 1.0,
                                    "note": "one frame at a time, cam.Org.z nudged by 0.1 every frame (kernel.cu:1727); eye-cone table "
                                            "rebuilt by a device kernel on the frame's stream, no host synchronisation"}
         extras["pipelined"] = {"frames_in_flight": 2, "ms_per_step": e_pl / args.steps * 1e3,

@@ -131,6 +131,8 @@ struct ConeSlot {
     bool valid = false;
     bool used = false;                    // read by some frame since it was built
     unsigned long long last_use = 0;      // ring sequence number of the last frame that read it
+    hipEvent_t built = nullptr;           // the build on the scene's table stream
+    bool build_pending = false;           // `built` not yet seen complete: readers wait on it (on the device)
 };
 
 struct rt_scene {
@@ -180,6 +182,8 @@ struct rt_scene {
     RtFrameAux h_aux;
     RtFrameAux *d_aux = nullptr;
     bool aux_valid = false;
+    // where the eye-cone builds run: beside the frames, not in front of them
+    hipStream_t table_stream = nullptr;
     // frames in flight
     hipEvent_t ring[RT_RING] = {};
     bool ring_used[RT_RING] = {};
@@ -222,6 +226,7 @@ int rt_scene_quiesce(rt_scene *s)
 {
     for (int i = 0; i < RT_RING; ++i)
         if (s->ring_used[i]) RT_HIP(hipEventSynchronize(s->ring[i]));
+    if (s->table_stream) RT_HIP(hipStreamSynchronize(s->table_stream));   // a table build still reading the list
     return RT_OK;
 }
 
@@ -268,8 +273,11 @@ extern "C" void rt_scene_destroy(rt_scene *s)
     if (s->d_box_spheres) (void)hipFree(s->d_box_spheres);
     if (s->d_tri9) (void)hipFree(s->d_tri9);
     if (s->d_light_tabs) (void)hipFree(s->d_light_tabs);
-    for (ConeSlot &c : s->cones)
+    for (ConeSlot &c : s->cones) {
         if (c.buf) (void)hipFree(c.buf);
+        if (c.built) (void)hipEventDestroy(c.built);
+    }
+    if (s->table_stream) (void)hipStreamDestroy(s->table_stream);
     if (s->d_raygen) (void)hipFree(s->d_raygen);
     if (s->d_aux) (void)hipFree(s->d_aux);
     for (hipEvent_t e : s->ring)
@@ -304,7 +312,7 @@ static int build_eye_cones_into(rt_scene *s, const float org[3], float4 *buf, hi
 {
     const int n = s->n_spheres;
     if (((n + 63) & ~63) <= RT_EYE_DEVICE_MAX) {
-        RT_HIP(rt_eye_cones_launch(s->d_spheres, n, org, buf, stream));
+        RT_HIP(rt_eye_cones_launch(s->d_spheres, n, org, buf, 1024, stream));
         return RT_OK;
     }
     const int n_pad = (n + 63) & ~63, nb = n_pad / RT_BLOCK;
@@ -350,17 +358,35 @@ static int rt_scene_prepare_eye(rt_scene *s, const float org[3], hipStream_t str
         RT_HIP(hipMalloc((void **)&c.buf, sizeof(float4) * total));
         c.cap = total;
         s->epoch++;
-    } else if (c.used && !host_build) {
-        // order the rebuild after the last frame that read this slot -- on the device only
-        if (s->ring_seq - c.last_use <= RT_RING) RT_HIP(hipStreamWaitEvent(stream, s->ring[c.last_use % RT_RING], 0));
-        else {
-            const int rc = stream_wait_all_frames(s, stream);
-            if (rc != RT_OK) return rc;
-        }
     }
     c.valid = false;
-    const int rc = build_eye_cones_into(s, org, c.buf, stream);
-    if (rc != RT_OK) return rc;
+    if (host_build) {
+        const int rc = build_eye_cones_into(s, org, c.buf, stream);
+        if (rc != RT_OK) return rc;
+        c.build_pending = false;
+    } else {
+        // On the scene's table stream, so that the build of frame k+1's table runs beside frame
+        // k's kernel instead of in front of frame k+1's (one small workgroup; a moving camera
+        // then costs the frames nothing but an event wait). Ordered, on the device only, after
+        // the last frame that read this slot and after a sphere-table upload still in flight.
+        if (!s->table_stream) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            RT_HIP(hipStreamCreateWithPriority(&s->table_stream, hipStreamNonBlocking, hi));
+        }
+        if (!c.built) RT_HIP(hipEventCreateWithFlags(&c.built, hipEventDisableTiming));
+        if (c.used) {
+            if (s->ring_seq - c.last_use <= RT_RING) RT_HIP(hipStreamWaitEvent(s->table_stream, s->ring[c.last_use % RT_RING], 0));
+            else {
+                const int rc = stream_wait_all_frames(s, s->table_stream);
+                if (rc != RT_OK) return rc;
+            }
+        }
+        if (s->stage_busy) RT_HIP(hipStreamWaitEvent(s->table_stream, s->stage_done, 0));
+        RT_HIP(rt_eye_cones_launch(s->d_spheres, s->n_spheres, org, c.buf, 256, s->table_stream));
+        RT_HIP(hipEventRecord(c.built, s->table_stream));
+        c.build_pending = true;
+    }
     memcpy(c.org, org, sizeof c.org);
     c.gen = s->sphere_gen;
     c.valid = true;
@@ -1099,6 +1125,12 @@ extern "C" int rt_scene_render(rt_scene *s, const rt_frame_desc *fd, void *strea
         rt_ray_origin(fd, org);
         rc = rt_scene_prepare_eye(s, org, stream, &slot);
         if (rc != RT_OK) return rc;
+    }
+    if (slot >= 0 && s->cones[slot].build_pending) {   // the table's build (table stream) precedes its readers
+        ConeSlot &c = s->cones[slot];
+        if (hipEventQuery(c.built) == hipSuccess) c.build_pending = false;
+        else RT_HIP(hipStreamWaitEvent(stream, c.built, 0));
+        (void)hipGetLastError();
     }
     RtFrameConsts fc;
     rc = rt_build_frame_consts(s, fd, slot >= 0 ? s->cones[slot].buf : nullptr, &fc);

@@ -122,7 +122,7 @@ static int build_graph(rt_frame_graph *g, hipStream_t stream)
         memset(&g->build_params, 0, sizeof g->build_params);
         const void *func;
         unsigned lds;
-        rt_eye_cones_kernel_config(n, &func, &g->build_params.gridDim, &g->build_params.blockDim, &lds);
+        rt_eye_cones_kernel_config(n, 1024, &func, &g->build_params.gridDim, &g->build_params.blockDim, &lds);
         g->build_params.func = const_cast<void *>(func);
         g->build_params.sharedMemBytes = lds;
         void *args[] = {&g->build_tab, &g->build_n, &g->build_org[0], &g->build_org[1], &g->build_org[2], &g->cones};

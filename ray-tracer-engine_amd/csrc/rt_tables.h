@@ -14,8 +14,9 @@ void rt_build_light_columns(const float4 *tab, int n, const float u[3], float4 *
 void rt_build_eye_cones_host(const float4 *tab, int n, const float org[3], float4 *sorted, float4 *blocks, int *orig);
 
 size_t rt_eye_cones_size(int n);   // float4 units: [n_pad entries][2 per block][n_pad ints]
-// Build the table on the device, on `stream` (tab: the list-order table in device memory).
-hipError_t rt_eye_cones_launch(const float4 *tab, int n, const float org[3], float4 *out, hipStream_t stream);
+// Build the table on the device, on `stream`, with one workgroup of `threads` (a multiple of 64, <= 1024)
+// (tab: the list-order table in device memory).
+hipError_t rt_eye_cones_launch(const float4 *tab, int n, const float org[3], float4 *out, int threads, hipStream_t stream);
 // The same launch as a graph kernel node: function, geometry and dynamic LDS; the arguments are
 // (const float4 *tab, int n, float ox, float oy, float oz, float4 *out).
-void rt_eye_cones_kernel_config(int n, const void **func, dim3 *grid, dim3 *block, unsigned *lds_bytes);
+void rt_eye_cones_kernel_config(int n, int threads, const void **func, dim3 *grid, dim3 *block, unsigned *lds_bytes);

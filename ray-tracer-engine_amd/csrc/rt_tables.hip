@@ -314,18 +314,21 @@ void rt_build_eye_cones_host(const float4 *tab, int n, const float org[3], float
     }
 }
 
-// The same table built by one 1024-thread workgroup: keys into LDS, bitonic sort, entries out,
-// then 16 lanes per block reduce their members' directions and angles with shuffles.
+// The same table built by ONE workgroup (any multiple of 64 threads up to 1024): keys into LDS,
+// bitonic sort, entries out, then 16 lanes per block reduce their members' directions and
+// angles with shuffles. 1024 threads when the build is a node in front of a graph's passes;
+// 256 when it runs on the scene's table stream beside the previous frame's kernel (four waves
+// find room on a CU that the frame kernel has filled to 24 of its 32 wave slots).
 __global__ __launch_bounds__(1024) void rt_eye_cones_kernel(const float4 *__restrict__ tab, int n, float ox, float oy, float oz,
                                                             float4 *__restrict__ out)
 {
     extern __shared__ unsigned long long keys[];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int n_pad = (n + 63) & ~63, nb = n_pad / RT_BLOCK;
     int P = 64;
     while (P < n_pad) P <<= 1;
     const float org[3] = {ox, oy, oz};
-    for (int i = tid; i < P; i += 1024) {
+    for (int i = tid; i < P; i += nt) {
         unsigned long long key = ~0ull;   // padding sorts last
         if (i < n) key = ((unsigned long long)cone_key(cone_entry(tab[i], org)) << 32) | (unsigned)i;
         keys[i] = key;
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(1024) void rt_eye_cones_kernel(const float4 *__rest
     __syncthreads();
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (P >> 1); t += 1024) {
+            for (int t = tid; t < (P >> 1); t += nt) {
                 const int i = 2 * t - (t & (j - 1)), l = i + j;
                 const unsigned long long a = keys[i], b = keys[l];
                 const bool up = (i & k) == 0;
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(1024) void rt_eye_cones_kernel(const float4 *__rest
     }
     float4 *sorted = out, *blocks = out + n_pad;
     int *orig = reinterpret_cast<int *>(out + n_pad + 2 * nb);
-    for (int i = tid; i < n_pad; i += 1024) {
+    for (int i = tid; i < n_pad; i += nt) {
         const unsigned long long key = keys[i];
         const bool have = key != ~0ull;
         const int idx = (int)(unsigned)(key & 0xffffffffu);
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(1024) void rt_eye_cones_kernel(const float4 *__rest
     }
     // blocks: RT_BLOCK consecutive lanes per block (RT_BLOCK divides 64: a group never straddles a wave)
     const int sub = tid % RT_BLOCK, grp = tid / RT_BLOCK;
-    for (int b0 = 0; b0 < nb; b0 += 1024 / RT_BLOCK) {
+    for (int b0 = 0; b0 < nb; b0 += nt / RT_BLOCK) {
         const int b = b0 + grp;
         const bool live = b < nb;                      // whole groups leave together; shuffles stay inside a group
         const int i = (live ? b : 0) * RT_BLOCK + sub;
@@ -416,24 +419,24 @@ size_t rt_eye_cones_size(int n)
     return n_pad + 2 * nb + (n_pad + 3) / 4;
 }
 
-void rt_eye_cones_kernel_config(int n, const void **func, dim3 *grid, dim3 *block, unsigned *lds_bytes)
+void rt_eye_cones_kernel_config(int n, int threads, const void **func, dim3 *grid, dim3 *block, unsigned *lds_bytes)
 {
     const int n_pad = (n + 63) & ~63;
     int P = 64;
     while (P < n_pad) P <<= 1;
     *func = (const void *)rt_eye_cones_kernel;
     *grid = dim3(1);
-    *block = dim3(1024);
+    *block = dim3(threads);
     *lds_bytes = (unsigned)P * (unsigned)sizeof(unsigned long long);
 }
 
-hipError_t rt_eye_cones_launch(const float4 *tab, int n, const float org[3], float4 *out, hipStream_t stream)
+hipError_t rt_eye_cones_launch(const float4 *tab, int n, const float org[3], float4 *out, int threads, hipStream_t stream)
 {
-    if (n < 1 || n > RT_EYE_DEVICE_MAX) return hipErrorInvalidValue;
+    if (n < 1 || n > RT_EYE_DEVICE_MAX || threads < 64 || threads > 1024 || threads % 64) return hipErrorInvalidValue;
     const void *func;
     dim3 grid, block;
     unsigned lds;
-    rt_eye_cones_kernel_config(n, &func, &grid, &block, &lds);
+    rt_eye_cones_kernel_config(n, threads, &func, &grid, &block, &lds);
     hipLaunchKernelGGL(rt_eye_cones_kernel, grid, block, lds, stream, tab, n, org[0], org[1], org[2], out);
     return hipGetLastError();
 }
