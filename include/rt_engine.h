@@ -341,6 +341,46 @@ int rt_graph_set_camera(rt_frame_graph *g, const rt_camera *cam);
 void rt_graph_destroy(rt_frame_graph *g);
 
 /* ------------------------------------------------------------------ *
+ * Several GPUs of one node, one process (BASELINE C5): *
+ * the frame's rows are dealt to the devices in 16-row blocks           *
+ * round-robin, every device renders its rows as 3 bytes per pixel,     *
+ * ONE RCCL gather over xGMI brings them to the first device, and one   *
+ * small kernel there scatters the rows home and widens them to the     *
+ * 0x00RRGGBB words setPixelBuff() consumes (kernel.cu:1788). update()  *
+ * takes this path when rt_config_set_gpus(n > 1) was called (or the    *
+ * application's environment says RT_GPUS=n).                           *
+ * ------------------------------------------------------------------ */
+typedef struct rt_multi rt_multi;
+enum { RT_MULTI_AUTO = 0,       /* RCCL for distinct devices                                         */
+       RT_MULTI_RCCL = 1,       /* ncclCommInitAll + one ncclGather per frame (librccl loaded with dlopen) */
+       RT_MULTI_PEER_COPY = 2   /* the first device pulls the rows with hipMemcpyPeerAsync (SDMA over xGMI);
+                                   accepts the same device several times (one-GPU rehearsal of the path) */ };
+rt_multi *rt_multi_create(int n_gpus);                       /* devices 0 .. n_gpus-1, RT_MULTI_AUTO; NULL on failure */
+int rt_multi_create_ex(const int *devices, int n, int transport, rt_multi **out);
+void rt_multi_destroy(rt_multi *m);
+int rt_multi_device_count(const rt_multi *m);
+int rt_multi_transport(const rt_multi *m);
+rt_scene *rt_multi_scene(rt_multi *m, int i, int *device);   /* the i-th device's scene (hipSetDevice(*device) before using it) */
+/* the same scene on every device (rt_scene_set_* per device) */
+int rt_multi_set_spheres(rt_multi *m, const rt_sphere *host_spheres, int n);
+int rt_multi_set_planes(rt_multi *m, const rt_plane *host_planes, int n);
+int rt_multi_set_cubes(rt_multi *m, const rt_cube *host_cubes, int n);
+int rt_multi_set_mesh(rt_multi *m, const rt_mesh *mesh);
+int rt_multi_set_texture(rt_multi *m, const float *r, const float *g, const float *b, int w, int h);
+int rt_multi_set_sky(rt_multi *m, const rt_sphere *box, const float *r, const float *g, const float *b, int w, int h);
+int rt_multi_set_lights(rt_multi *m, const rt_light *lights, int n);
+/* One frame (width, height, aspect, cam and opts.spp / cull / tile of `fd`; its output pointers and
+ * row bands are ignored). The assembled frame lands in `pixels_dev0` (memory of the first device) or,
+ * if that is NULL, in an internal buffer (rt_multi_frame). Asynchronous; two frames may be in flight. */
+int rt_multi_render(rt_multi *m, const rt_frame_desc *fd, uint32_t *pixels_dev0);
+int rt_multi_sync(rt_multi *m);                              /* wait for every frame enqueued so far */
+const uint32_t *rt_multi_frame(const rt_multi *m);           /* device pointer of the last assembled frame */
+int rt_multi_download(rt_multi *m, uint32_t *host);          /* sync + copy the last frame to host memory */
+int rt_config_set_gpus(int n);                               /* update(): devices used per frame; default 1. n < 0:
+                                                                rehearsal of the path on one GPU -- |n| shares of the
+                                                                frame, all on device 0, RT_MULTI_PEER_COPY */
+
+/* ------------------------------------------------------------------ *
  * Introspection / diagnostics                                         *
  * ------------------------------------------------------------------ */
 int rt_abi_version(void);

@@ -204,6 +204,24 @@ def load_library():
         "rt_debug_intersect": (ci, [C.POINTER(Sphere), C.POINTER(Ray), ci, C.POINTER(ci), fp]),
         "rt_debug_light": (ci, [C.POINTER(Sphere), ci, C.POINTER(Vec3), C.POINTER(Vec3), C.POINTER(Light), ci, fp, fp]),
         "rt_debug_shortcuts": (ci, [ci, C.c_uint, C.c_longlong, C.POINTER(C.c_ulonglong)]),
+        "rt_multi_create": (vp, [ci]),
+        "rt_multi_create_ex": (ci, [C.POINTER(ci), ci, ci, C.POINTER(vp)]),
+        "rt_multi_destroy": (None, [vp]),
+        "rt_multi_device_count": (ci, [vp]),
+        "rt_multi_transport": (ci, [vp]),
+        "rt_multi_scene": (vp, [vp, ci, C.POINTER(ci)]),
+        "rt_multi_set_spheres": (ci, [vp, C.POINTER(Sphere), ci]),
+        "rt_multi_set_planes": (ci, [vp, C.POINTER(Plane), ci]),
+        "rt_multi_set_cubes": (ci, [vp, C.POINTER(Cube), ci]),
+        "rt_multi_set_mesh": (ci, [vp, C.POINTER(Mesh)]),
+        "rt_multi_set_texture": (ci, [vp, fp, fp, fp, ci, ci]),
+        "rt_multi_set_sky": (ci, [vp, C.POINTER(Sphere), fp, fp, fp, ci, ci]),
+        "rt_multi_set_lights": (ci, [vp, C.POINTER(Light), ci]),
+        "rt_multi_render": (ci, [vp, C.POINTER(FrameDesc), vp]),
+        "rt_multi_sync": (ci, [vp]),
+        "rt_multi_frame": (vp, [vp]),
+        "rt_multi_download": (ci, [vp, vp]),
+        "rt_config_set_gpus": (ci, [ci]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError here = header/library mismatch: fail loudly

@@ -941,8 +941,8 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, const floa
             const int b = o.interleave_rows > 0 ? o.interleave_rows : 16;
             owns_rows = b > 0 && (long long)o.interleave_index * b < fd->height;
         }
-        if (owns_rows && !fd->pixels && !o.rgba) {
-            rt_set_error("rt_scene_render: no output buffer (pixels and opts.rgba are both null)");
+        if (owns_rows && !fd->pixels && !o.rgba && !o.packed24) {
+            rt_set_error("rt_scene_render: no output buffer (pixels, opts.rgba and opts.packed24 are all null)");
             return RT_ERR_INVALID;
         }
     }

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/rt_engine.h"
 #include "../../include/rt_kernel.h"
@@ -74,6 +75,7 @@ static float aspect = 0.f;
 // rt_config_set_assets(), else the environment of the APPLICATION SHELL (RT_OBJECT_TEXTURE,
 // RT_SKY_TEXTURE, RT_MESH_OBJ, read once in onStart), else the synthetic stand-ins
 static std::string cfg_object_texture, cfg_sky_texture, cfg_mesh_obj;
+static int cfg_gpus = 0;                 // 0: not set (RT_GPUS of the application's environment, else 1)
 static int cfg_sphere_count = 1024;      // the reference ships 0 (kernel.cu:1231); BASELINE configs set it
 static unsigned int cfg_seed = 1;        // un-seeded MSVC rand() starts from state 1
 
@@ -105,6 +107,12 @@ extern "C" int rt_config_set_assets(const char *object_texture, const char *sky_
     cfg_object_texture = object_texture ? object_texture : "";
     cfg_sky_texture = sky_texture ? sky_texture : "";
     cfg_mesh_obj = mesh_obj ? mesh_obj : "";
+    return RT_OK;
+}
+extern "C" int rt_config_set_gpus(int n)
+{
+    if (n < -64 || n > 64) return RT_ERR_INVALID;
+    cfg_gpus = n;   // n < 0: rehearsal, |n| shares of the frame all rendered on device 0 (peer-copy transport)
     return RT_OK;
 }
 extern "C" rt_camera *rt_config_camera(void) { return &cam; }
@@ -178,6 +186,79 @@ static void release_frame_buffers()
     fr.width = fr.height = 0;
 }
 
+// The frame on several GPUs of the node (rt_multi.hip): the scene graph is mirrored to every
+// device when it changes, each device renders its 16-row blocks, one RCCL gather, rows scattered
+// home on the first device; then the same D2H + setPixelBuff as the single-GPU path.
+static struct MultiRes {
+    rt_multi *m = nullptr;
+    int gpus = 0;
+    const void *tex_key = nullptr, *sky_key = nullptr, *mesh_key = nullptr;
+    std::vector<char> spheres_prev, lights_prev;
+    int planes_prev = -1, cubes_prev = -1;
+} mr;
+
+static int update_multi(int gpus, int width, int height)
+{
+    if (!mr.m || mr.gpus != gpus) {
+        if (mr.m) rt_multi_destroy(mr.m);
+        mr = MultiRes();
+        if (gpus > 0) {
+            mr.m = rt_multi_create(gpus);
+        } else {
+            std::vector<int> same((size_t)-gpus, 0);
+            if (rt_multi_create_ex(same.data(), -gpus, RT_MULTI_PEER_COPY, &mr.m) != RT_OK) mr.m = nullptr;
+        }
+        if (!mr.m) return RT_ERR_HIP;
+        mr.gpus = gpus;
+    }
+    int rc = RT_OK;
+    const size_t sbytes = sizeof(rt_sphere) * (size_t)(objs->sphere_count > 0 ? objs->sphere_count : 0);
+    if (mr.spheres_prev.size() != sbytes || (sbytes && memcmp(mr.spheres_prev.data(), objs->d_spheres, sbytes) != 0)) {
+        if ((rc = rt_multi_set_spheres(mr.m, objs->d_spheres, objs->sphere_count)) != RT_OK) return rc;
+        mr.spheres_prev.assign((const char *)objs->d_spheres, (const char *)objs->d_spheres + sbytes);
+    }
+    const size_t lbytes = sizeof(rt_light) * (size_t)light_size;
+    if (mr.lights_prev.size() != lbytes || memcmp(mr.lights_prev.data(), lights, lbytes) != 0) {
+        if ((rc = rt_multi_set_lights(mr.m, lights, light_size)) != RT_OK) return rc;
+        mr.lights_prev.assign((const char *)lights, (const char *)lights + lbytes);
+    }
+    const rt_sprite *t = objs->texture;
+    if (t && t->rBuff->data != mr.tex_key) {
+        if ((rc = rt_multi_set_texture(mr.m, t->rBuff->data, t->gBuff->data, t->bBuff->data, t->width, t->height)) != RT_OK) return rc;
+        mr.tex_key = t->rBuff->data;
+    }
+    const rt_sprite *k = Skybox->skyboxTex;
+    if (k->rBuff->data != mr.sky_key) {
+        if ((rc = rt_multi_set_sky(mr.m, Skybox->box, k->rBuff->data, k->gBuff->data, k->bBuff->data, k->width, k->height)) != RT_OK) return rc;
+        mr.sky_key = k->rBuff->data;
+    }
+    if (objs->mesh1 != mr.mesh_key) {
+        if ((rc = rt_multi_set_mesh(mr.m, (objs->mesh1 && objs->mesh1->bvhbox_count > 0) ? objs->mesh1 : nullptr)) != RT_OK) return rc;
+        mr.mesh_key = objs->mesh1;
+    }
+    if (objs->plane_count != mr.planes_prev) {
+        if ((rc = rt_multi_set_planes(mr.m, objs->d_planes, objs->plane_count)) != RT_OK) return rc;
+        mr.planes_prev = objs->plane_count;
+    }
+    if (objs->cube_count != mr.cubes_prev) {
+        if ((rc = rt_multi_set_cubes(mr.m, objs->d_cubes, objs->cube_count)) != RT_OK) return rc;
+        mr.cubes_prev = objs->cube_count;
+    }
+    rt_frame_desc fd;
+    memset(&fd, 0, sizeof fd);
+    fd.struct_size = sizeof fd;
+    fd.width = width;
+    fd.height = height;
+    fd.aspect = aspect;
+    fd.cam = cam;
+    fd.opts.struct_size = sizeof fd.opts;
+    fd.opts.cull = -1;
+    if ((rc = rt_multi_render(mr.m, &fd, fr.d_pixels)) != RT_OK) return rc;
+    if ((rc = rt_multi_sync(mr.m)) != RT_OK) return rc;
+    RT_HIP(hipMemcpy(fr.h_pixels, fr.d_pixels, sizeof(uint32_t) * (size_t)width * (size_t)height, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
 // update, kernel.cu:1762-1792
 void update()
 {
@@ -206,6 +287,25 @@ void update()
         checkHipErrors(hipHostMalloc((void **)&fr.h_pixels, pixelSize, hipHostMallocDefault));
         fr.width = width;
         fr.height = height;
+    }
+
+    {   // several GPUs: rt_config_set_gpus(n), else RT_GPUS of the application's environment (read per frame: cheap)
+        int gpus = cfg_gpus;
+        if (gpus == 0) {
+            const char *e = getenv("RT_GPUS");
+            gpus = (e && *e) ? atoi(e) : 1;
+        }
+        if (gpus > 1 || gpus < -1) {
+            (void)hipSetDevice(0);
+            const int rc = update_multi(gpus, width, height);
+            if (rc != RT_OK) {
+                fprintf(stderr, "update: %s\n", rt_last_error());
+                rt_check(rc, "rt_multi_render", __FILE__, __LINE__);
+                return;
+            }
+            setPixelBuff(fr.h_pixels);                                    // kernel.cu:1788
+            return;
+        }
     }
 
     // The frame is rendered in row bands (kernel.cu:1783 is one launch; the bands are the same

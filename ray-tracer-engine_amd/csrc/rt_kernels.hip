@@ -1882,8 +1882,10 @@ static RtTraceFn trace_fn(int tile_w, int cull, int mode, int table_in_lds, int 
 // stream capture or graph construction.
 extern "C" hipError_t rt_dev_prepare(void)
 {
-    static bool done = false;
-    if (done) return hipSuccess;
+    static unsigned long long done = 0;   // one bit per device: function attributes belong to a device's code object
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorNoDevice;
+    if (dev < 64 && ((done >> dev) & 1ull)) return hipSuccess;
     for (int cull = 0; cull < 2; ++cull)
         for (int mode = 0; mode < 4; ++mode)
             for (int feat = 0; feat < 3; ++feat)
@@ -1893,7 +1895,7 @@ extern "C" hipError_t rt_dev_prepare(void)
                     const hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                     if (e != hipSuccess) return e;
                 }
-    done = true;
+    if (dev < 64) done |= 1ull << dev;
     return hipSuccess;
 }
 

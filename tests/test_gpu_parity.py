@@ -700,3 +700,75 @@ def test_packed24_is_the_packed_frame_without_its_zero_byte(rt, gpu):
     assert torch.equal(rd.unpack_rgb24(out["packed24"], 164), out["packed"])
     with pytest.raises(rt.RtError):
         sc.render(162, 40, want_packed24=True)
+
+
+# ---------------------------------------------------------------- several GPUs from the C ABI
+def _multi_scene(rt, lib, m, inp):
+    fp = C.POINTER(C.c_float)
+    ptr = lambda a: a.ctypes.data_as(fp)
+    assert lib.rt_multi_set_spheres(m, inp.spheres, inp.n) == 0
+    h, w = inp.tex[0].shape
+    assert lib.rt_multi_set_texture(m, ptr(inp.tex[0]), ptr(inp.tex[1]), ptr(inp.tex[2]), w, h) == 0
+    h, w = inp.sky[0].shape
+    assert lib.rt_multi_set_sky(m, C.byref(inp.sky_box), ptr(inp.sky[0]), ptr(inp.sky[1]), ptr(inp.sky[2]), w, h) == 0
+    assert lib.rt_multi_set_lights(m, inp.lights, 3) == 0
+
+
+@pytest.mark.parametrize("shares,w,h,n", [(1, 160, 90, 256), (2, 160, 90, 1024), (3, 164, 100, 256), (8, 160, 90, 1024),
+                                          (8, 1920, 1080, 256)])
+def test_multi_device_frame_from_the_c_abi(rt, gpu, shares, w, h, n):
+    """rt_multi_*: the frame split into 16-row blocks dealt round-robin, every share rendered as
+    24-bit rows, gathered to the first device and scattered home by rt_scatter_rows24 -- equal to
+    the single-GPU frame bit for bit. One GPU here, so `shares` > 1 uses the same device several
+    times with the peer-copy transport (everything but the RCCL call itself runs); one share goes
+    through RT_MULTI_RCCL: librccl is loaded with dlopen and ncclCommInitAll runs."""
+    import torch
+    lib = rt.load_library()
+    inp = Inputs(rt, n)
+    want = inp.scene().render(w, h, want_rgba=False)["packed"]
+    m = C.c_void_p()
+    devs = (C.c_int * shares)(*([0] * shares))
+    transport = 1 if shares == 1 else 2
+    assert lib.rt_multi_create_ex(devs, shares, transport, C.byref(m)) == 0, lib.rt_last_error()
+    assert lib.rt_multi_device_count(m) == shares and lib.rt_multi_transport(m) == transport
+    _multi_scene(rt, lib, m, inp)
+    sc = rt.Scene()
+    fd = sc.frame_desc(w, h)
+    out = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    cams = []
+    for k in range(5):                                   # frames in flight on both buffer sets, camera moving
+        cam = rt.default_camera()
+        cam.Org.z = 10.0 + 0.1 * k
+        cams.append(cam)
+        fd.cam = cam
+        assert lib.rt_multi_render(m, C.byref(fd), out.data_ptr() if k == 4 else None) == 0, lib.rt_last_error()
+    host = np.zeros((h, w), dtype=np.uint32)
+    assert lib.rt_multi_download(m, host.ctypes.data) == 0
+    want4 = inp.scene().render(w, h, want_rgba=False, cam=cams[4])["packed"]
+    torch.cuda.synchronize()
+    assert torch.equal(out, want4) and np.array_equal(host, want4.cpu().numpy().view(np.uint32))
+    fd.cam = rt.default_camera()
+    assert lib.rt_multi_render(m, C.byref(fd), None) == 0
+    assert lib.rt_multi_download(m, host.ctypes.data) == 0
+    assert np.array_equal(host, want.cpu().numpy().view(np.uint32))
+    lib.rt_multi_destroy(m)
+
+
+def test_update_on_several_shares(rt, gpu):
+    """update() with rt_config_set_gpus: the presented frame equals the oracle's (rehearsed on one
+    GPU: three shares of the frame on device 0)."""
+    import oracle_py
+    lib = rt.load_library()
+    assert lib.rt_config_set_sphere_count(256) == 0 and lib.rt_config_set_seed(1) == 0
+    assert lib.rt_config_set_gpus(-3) == 0
+    try:
+        lib.rt_on_start()
+        inp = Inputs(rt, 256)
+        for (w, h) in ((160, 90), (96, 54)):
+            assert lib.rt_offscreen_resize(w, h) == 0
+            lib.rt_update()
+            got = np.ctypeslib.as_array(lib.rt_offscreen_pixels(), shape=(h, w)).copy()
+            _, want, _ = inp.oracle_render(oracle_py, w, h)
+            assert np.array_equal(got, want), (w, h)
+    finally:
+        lib.rt_config_set_gpus(0)
