@@ -376,6 +376,10 @@ int rt_multi_render(rt_multi *m, const rt_frame_desc *fd, uint32_t *pixels_dev0)
 int rt_multi_sync(rt_multi *m);                              /* wait for every frame enqueued so far */
 const uint32_t *rt_multi_frame(const rt_multi *m);           /* device pointer of the last assembled frame */
 int rt_multi_download(rt_multi *m, uint32_t *host);          /* sync + copy the last frame to host memory */
+/* The root side of the exchange alone, for hosts that run the gather themselves (one process per GPU:
+ * bench.py under torch.distributed): `recv` = n slots of slot_rows rows of width*3 bytes, slot r being
+ * what rank r rendered with interleave (n, r, 16) into opts.packed24; `frame` = width*height words. */
+int rt_assemble_rows24(const void *recv, uint32_t *frame, int width, int height, int n, int slot_rows, void *stream);
 int rt_config_set_gpus(int n);                               /* update(): devices used per frame; default 1. n < 0:
                                                                 rehearsal of the path on one GPU -- |n| shares of the
                                                                 frame, all on device 0, RT_MULTI_PEER_COPY */

@@ -222,6 +222,7 @@ def load_library():
         "rt_multi_frame": (vp, [vp]),
         "rt_multi_download": (ci, [vp, vp]),
         "rt_config_set_gpus": (ci, [ci]),
+        "rt_assemble_rows24": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError here = header/library mismatch: fail loudly

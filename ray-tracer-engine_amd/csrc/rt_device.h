@@ -25,6 +25,14 @@
 #define RT_MIN_WAVES_ONE_SAMPLE 6 // the one-sample kernels without a mesh (every BASELINE config at 1 spp, and each pass of the
                                // hipGraph frame) fit 80 registers without a spill: 6 waves per SIMD
 #endif
+#ifndef RT_MIN_WAVES_MESH
+#define RT_MIN_WAVES_MESH 5      // one-sample kernels with the triangle-mesh branches: 96 registers. The compiler then spills
+                                 // 2 of them (12 B of scratch per lane); measured against the 4-wave budget, which spills
+                                 // nothing: 2.14 vs 2.25 ms on the 4K / 7 520-triangle frame, so 5 it is
+#endif
+#ifndef RT_MIN_WAVES_MESH_MULTI
+#define RT_MIN_WAVES_MESH_MULTI 4 // ... with a sample loop or work counters on top: 128 registers, no spill
+#endif
 #ifndef RT_WAVES_PER_WG
 #define RT_WAVES_PER_WG 4         // wave tiles per workgroup when the table is staged in LDS (1, 2 or 4)
 #endif

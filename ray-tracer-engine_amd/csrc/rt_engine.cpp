@@ -1062,10 +1062,6 @@ int rt_frame_kernel_choice(const rt_scene *s, const rt_frame_desc *fd, RtKernelC
         return RT_ERR_UNSUPPORTED;
     }
 #endif
-    if (kc->feat == 2 && (kc->tile != 8 || fd->opts.stats)) {
-        rt_set_error("rt_scene_render: scenes with a triangle mesh render with the default tile and without stats");
-        return RT_ERR_UNSUPPORTED;
-    }
     if (fd->opts.stats && fd->opts.force_slow_path) {
         rt_set_error("rt_scene_render: stats and force_slow_path exclude each other");
         return RT_ERR_UNSUPPORTED;

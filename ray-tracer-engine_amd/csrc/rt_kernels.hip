@@ -902,7 +902,7 @@ __device__ __forceinline__ void shadow_test(const RayK &sr, float4 s, bool &shad
 // MULTI: the launch may take several samples per pixel (rt_launch_opts.spp > 1). The
 // one-sample kernel has no sample loop: 74 -> 22 spilled scalars and 15 fewer vector registers.
 template <int TW, bool CULL, int MODE, bool TABLDS, int FEAT = 0, bool MULTI = true>
-__global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (!MULTI && FEAT < 2 && !TABLDS) ? RT_MIN_WAVES_ONE_SAMPLE : RT_MIN_WAVES_PER_SIMD) void rt_trace_tiles(const RtFrameConsts fc,
+__global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? (MODE == 1 ? 3 : (MULTI || TABLDS) ? RT_MIN_WAVES_MESH_MULTI : RT_MIN_WAVES_MESH) : (!MULTI && !TABLDS) ? RT_MIN_WAVES_ONE_SAMPLE : RT_MIN_WAVES_PER_SIMD) void rt_trace_tiles(const RtFrameConsts fc,
                                                                      const float4 *__restrict__ spheres)
 {
     constexpr int STATS = (MODE == 1) ? 1 : (MODE == 3) ? 2 : 0;
@@ -1072,7 +1072,6 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (!MULTI && FEA
         float hcx = 0.f, hcy = 0.f, hcz = 0.f;   // centre of the closest sphere
         int hkind = 1;                           // 0 triangle, 1 sphere, 2 plane, 3 cube (kernel.cu:1376)
         int htri = 0;
-        float hnu = 0.f, hnv = 0.f;
         if (MESH) {
             // triangles through the flat list of leaf boxes, kernel.cu:1293-1328 (before
             // the spheres, as there): a lane tests a leaf's triangles iff its ray hits the box
@@ -1094,9 +1093,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (!MULTI && FEA
                             float t, u, v;
                             if (bh && tri_intersect(O, D, tv, tv + 3, tv + 6, t, u, v) && t < nt) {
                                 nt = t;
-                                hnu = u;
-                                hnv = v;
-                                htri = bx.start + base + i;   // position in tri_idx; resolved when shading
+                                htri = bx.start + base + i;   // position in tri_idx; resolved when shading (u, v too)
                                 hkind = 0;
                             }
                         }
@@ -1205,6 +1202,10 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (!MULTI && FEA
             V3 hp = new_org;              // what start_O is offset from
             if (MESH && hkind == 0) {     // triangle, kernel.cu:1378-1393
                 const RtTriDev *tp = ax->tris + ax->tri_idx[htri];
+                // the barycentrics of the winning triangle: the same operations on the same operands as
+                // in the loop above (which does not carry them along)
+                float hnt, hnu = 0.f, hnv = 0.f;
+                (void)tri_intersect(O, D, tp->p0, tp->p1, tp->p2, hnt, hnu, hnv);
                 const float w0 = 1 - hnu - hnv;
                 if (fc.flags & RT_FLAG_MESH_NORMALS) {
                     normal = V3{(tp->vn[0] * w0 + tp->vn[3] * hnu) + tp->vn[6] * hnv,
@@ -1835,9 +1836,10 @@ typedef void (*RtTraceFn)(const RtFrameConsts, const float4 *);
 template <int TW, bool CULL, bool TABLDS, bool MULTI>
 static RtTraceFn trace_fn_mode_feat(int mode, int feat)
 {
-    if (feat == 2) {
-        if constexpr (TW == 8) {
+    if (feat == 2) {   // whole-table LDS staging and a sample loop together are not instantiated for mesh scenes
+        if constexpr (!(TABLDS && MULTI)) {
             if (mode == 0) return rt_trace_tiles<TW, CULL, 0, TABLDS, 2, MULTI>;
+            if (mode == 1) return rt_trace_tiles<TW, CULL, 1, TABLDS, 2, MULTI>;
             if (mode == 2) return rt_trace_tiles<TW, CULL, 2, TABLDS, 2, MULTI>;
         }
         return nullptr;
@@ -1904,7 +1906,7 @@ extern "C" hipError_t rt_dev_prepare(void)
 extern "C" hipError_t rt_dev_trace_config(const RtFrameConsts *fc, int tile_w, int cull, int mode, int table_in_lds, int feat,
                                           const void **func, dim3 *grid, dim3 *block, unsigned *lds_bytes)
 {
-    if (tile_w != 8) table_in_lds = 0;
+    if (tile_w != 8 || (feat == 2 && fc->spp > 1)) table_in_lds = 0;
     const RtTraceFn fn = trace_fn(tile_w, cull, mode, table_in_lds, feat, fc->spp > 1 ? 1 : 0);
     if (!fn) return hipErrorNotSupported;
     const int n_pad = (fc->n_spheres + 63) & ~63;

@@ -410,6 +410,23 @@ extern "C" int rt_multi_render(rt_multi *m, const rt_frame_desc *fd, uint32_t *p
     return RT_OK;
 }
 
+// The root side of the gather as one call, for hosts that run the exchange themselves (one process
+// per GPU under torch.distributed / MPI: bench.py): `recv` holds n slots of slot_rows rows of
+// width*3 bytes (slot r = what rank r rendered with interleave (n, r, 16) and opts.packed24);
+// `frame` receives the width*height words. On `stream`, current device.
+extern "C" int rt_assemble_rows24(const void *recv, uint32_t *frame, int width, int height, int n, int slot_rows, void *stream)
+{
+    if (!recv || !frame || width <= 0 || height <= 0 || width % 4 != 0 || n < 1 || slot_rows < 1) {
+        rt_set_error("rt_assemble_rows24: invalid argument");
+        return RT_ERR_INVALID;
+    }
+    const long long threads = (long long)(width / 4) * height;
+    hipLaunchKernelGGL(rt_scatter_rows24, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned *>(recv), reinterpret_cast<uint4 *>(frame), width, height, n, slot_rows);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
 // Wait for every frame enqueued so far (all devices).
 extern "C" int rt_multi_sync(rt_multi *m)
 {

@@ -65,7 +65,7 @@ def assemble_interleaved(gathered, height: int, block: int = 16, out=None) -> to
     if out is None:
         out = torch.empty((height, width), dtype=gathered[0].dtype, device=gathered[0].device)
     for r, g in enumerate(gathered):
-        idx = torch.as_tensor(interleaved_rows(height, r, world, block), device=g.device)
+        idx = torch.as_tensor(interleaved_rows(height, r, world, block), dtype=torch.int64, device=g.device)
         out.index_copy_(0, idx, g[: idx.numel()])
     return out
 
@@ -104,12 +104,19 @@ class InterleavedGather:
         src = torch.empty(height, dtype=torch.int64)
         for r in range(world):
             rows = interleaved_rows(height, r, world, block)
-            src[torch.as_tensor(rows)] = r * self.max_rows + torch.arange(len(rows))
+            src[torch.as_tensor(rows, dtype=torch.int64)] = r * self.max_rows + torch.arange(len(rows))
         self.src_rows = src.to(device)            # frame row y comes from recv.view(-1, W)[src_rows[y]]
         self.frame = torch.zeros((height, width), dtype=dtype, device=device)
         self.frame24 = torch.empty((height, self.row_words), dtype=dtype, device=device) if rgb24 else None
 
     def assemble(self) -> torch.Tensor:
+        if self.rgb24 and self.recv.is_cuda and self.block == 16:
+            # one kernel of the library: rows home and 24 -> 32 bits (rt_multi.hip, rt_scatter_rows24)
+            from . import load_library, _check
+            _check(load_library().rt_assemble_rows24(self.recv.data_ptr(), self.frame.data_ptr(), self.width, self.height,
+                                                     self.world, self.max_rows, torch.cuda.current_stream().cuda_stream),
+                   "rt_assemble_rows24")
+            return self.frame
         if self.rgb24:
             torch.index_select(self.recv.view(self.world * self.max_rows, -1), 0, self.src_rows, out=self.frame24)
             return unpack_rgb24(self.frame24, self.width, out=self.frame)

@@ -772,3 +772,22 @@ def test_update_on_several_shares(rt, gpu):
             assert np.array_equal(got, want), (w, h)
     finally:
         lib.rt_config_set_gpus(0)
+
+
+@pytest.mark.parametrize("world", [2, 5, 8])
+def test_root_side_assembly_kernel(rt, gpu, world):
+    """What bench.py's root does per frame at N > 1: the ranks' 24-bit rows (here rendered one after
+    the other on this GPU) sit in the gather's receive slots; rt_assemble_rows24 -- one kernel of the
+    library -- puts every row in place and widens it; the result is the single-GPU frame."""
+    import torch
+    from ray_tracer_engine_amd import distributed as rd
+    w, h, n = 160, 90, 256
+    sc = Inputs(rt, n).scene()
+    want = sc.render(w, h, want_rgba=False)["packed"]
+    root = rd.InterleavedGather(h, w, world, "cuda", 16, rgb24=True)
+    for r in range(world):
+        out = sc.render(w, h, interleave=(world, r, 16), want_packed24=True, want_rgba=False)
+        root.views[r][: out["packed24"].shape[0]].copy_(out["packed24"])
+    frame = root.assemble()
+    torch.cuda.synchronize()
+    assert torch.equal(frame, want)

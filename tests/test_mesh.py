@@ -136,13 +136,18 @@ def _render_both(rt, inp, mesh, w, h, **kw):
         sc.set_cubes(inp.cubes, inp.n_cubes)
     pm = rt.mesh_from_obj_text(mesh)
     sc.set_mesh(pm)
-    for cull in (True, False):
-        out = sc.render(w, h, cull=cull, cam=inp.cam)
+    # every way a mesh scene can be launched: culled / brute force, the four tile shapes, all shortcuts
+    # off, with the work counters, whole-table LDS staging
+    for opts in (dict(cull=True), dict(cull=False), dict(cull=True, tile=16), dict(cull=True, tile=32), dict(cull=False, tile=64),
+                 dict(cull=True, force_slow=True), dict(cull=True, want_stats=True), dict(cull=True, table_lds=True)) + tuple(kw.get("more", ())):
+        out = sc.render(w, h, cam=inp.cam, **opts)
         torch.cuda.synchronize()
         got = out["rgba"].cpu().numpy()
         bad = int((got.view(np.uint32) != rgba.view(np.uint32)).any(axis=2).sum())
-        assert bad == 0, (cull, bad)
-        assert np.array_equal(out["packed"].cpu().numpy().view(np.uint32), packed)
+        assert bad == 0, (opts, bad)
+        assert np.array_equal(out["packed"].cpu().numpy().view(np.uint32), packed), opts
+        if "stats" in out:
+            assert out["stats"]["hit_pixels"] == cnt["hit_pixels"]
     return cnt
 
 
