@@ -398,6 +398,36 @@ __device__ __forceinline__ bool intersect_tail(const RayK &r, const Quad &q, flo
     return false;
 }
 
+// The same tail with the lean square root and the lean divisions (see normalise_t above; both roots
+// divide by the same 2A, so the divisor's part of the expansion is shared). Safe range, per lane:
+// disc in [2^-96, 2^60], 2A in [2^-20, 2^20], both numerators between 2^-40 and 2^40 in magnitude --
+// anything else (a zero numerator in particular: the reference's `t == 0` clause) takes the IEEE forms.
+template <bool LEAN>
+__device__ __forceinline__ bool intersect_tail_t(const RayK &r, const Quad &q, float &t)
+{
+    if constexpr (!LEAN) {
+        return intersect_tail(r, q, t);
+    } else {
+        const float nb = -q.B;
+        const bool pre = (q.disc >= 0x1.0p-96f) & (q.disc <= 0x1.0p60f) & (r.a2 >= 0x1.0p-20f) & (r.a2 <= 0x1.0p20f);
+        if (__builtin_expect(!pre, 0)) return intersect_tail(r, q, t);
+        const float sq = lean_sqrt(q.disc);
+        const float n1 = nb + sq, n2 = nb - sq;
+        const bool safe = (__builtin_fminf(__builtin_fabsf(n1), __builtin_fabsf(n2)) >= 0x1.0p-40f) &
+                          (__builtin_fmaxf(__builtin_fabsf(n1), __builtin_fabsf(n2)) <= 0x1.0p40f);
+        if (__builtin_expect(!safe, 0)) return intersect_tail(r, q, t);
+        const LeanRcp ra(r.a2);
+        t = ra.divide(n1);
+        if (t >= RT_T_MIN) {           // t == 0 cannot happen here: |n1| >= 2^-40 and 2A <= 2^20
+            const float t2 = ra.divide(n2);
+            if (t > t2) t = t2;
+            return true;
+        }
+        return false;
+    }
+}
+
+
 // plane::intersect, kernel.cu:370-380
 __device__ __forceinline__ bool plane_intersect(const RtPlaneDev &p, V3 o, V3 d, float &t)
 {
@@ -604,7 +634,7 @@ __device__ __forceinline__ int build_list2(const float4 *tab, const RtFrameConst
                                            int *blist, const Beam &b, int lane, unsigned long long &n_cull,
                                            const float4 *__restrict__ csorted = nullptr,
                                            const float4 *__restrict__ cblocks = nullptr,
-                                           const int *__restrict__ corig = nullptr)
+                                           const int *__restrict__ corig = nullptr, bool stop_when_blocked = false)
 {
     constexpr bool COLUMNS = BLOCKS != 0;   // two float4 per block, table in global memory
     const float4 *__restrict__ gsorted = COLUMNS ? csorted : reinterpret_cast<const float4 *>(fc.sorted);
@@ -663,6 +693,12 @@ __device__ __forceinline__ int build_list2(const float4 *tab, const RtFrameConst
             count += __popcll(m);
             if (STATS == 1) n_cull += 64;
             cur = nxt;
+            // the caller only wants to know whether one sphere occludes the whole beam, and one does:
+            // the rest of the list is of no interest (the light adds nothing)
+            if (OCCL && stop_when_blocked && __any(blk)) {
+                wave_lds_sync();
+                return count | 0x40000000;
+            }
         }
         if (bbase + 64 < nb) wave_lds_sync();   // the next 64 blocks reuse the block list
     }
@@ -868,6 +904,7 @@ struct ShadowChain {
 // kernel.cu:1504-1508). Two shortcuts decide most entries without sqrt/div:
 // h < -h_sure puts t above RT_T_MIN (-B >= 2*h_sure and sqrt(disc) >= 0), and
 // "behind" (see RT_BEHIND_FACTOR) makes t strictly negative.
+template <bool LEAN = false>
 __device__ __forceinline__ void shadow_test(const RayK &sr, float4 s, bool &shadowed, bool force_slow)
 {
     const Quad q = quadratic(sr, s);
@@ -884,7 +921,7 @@ __device__ __forceinline__ void shadow_test(const RayK &sr, float4 s, bool &shad
     if (__any(need)) {
         if (need) {
             float t;
-            if (intersect_tail(sr, q, t)) shadowed = true;
+            if (intersect_tail_t<LEAN>(sr, q, t)) shadowed = true;
         }
     }
 }
@@ -915,6 +952,18 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
     constexpr bool LEAN = false;
 #else
     constexpr bool LEAN = CULL && !force_slow;
+#endif
+    // the lean tail of intersect(): for the primary rays; for the shadow rays it costs the one-sample
+    // kernel two spilled registers at its 6-waves-per-SIMD budget (measured: profiles/r02_variants.txt)
+#ifdef RT_NO_LEAN_PRIMARY_TAIL
+    constexpr bool LEAN_PRIMARY_TAIL = false;
+#else
+    constexpr bool LEAN_PRIMARY_TAIL = LEAN;
+#endif
+#ifdef RT_LEAN_SHADOW_TAIL
+    constexpr bool LEAN_SHADOW_TAIL = LEAN;
+#else
+    constexpr bool LEAN_SHADOW_TAIL = false;
 #endif
     constexpr int TH = 64 / TW;
     // Waves per workgroup: RT_WAVES_PER_WG share one staged table (TABLDS); with the table left
@@ -1127,7 +1176,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
             if (__any(need)) {
                 if (need) {
                     float t;
-                    if (intersect_tail(pr, q, t)) {
+                    if (intersect_tail_t<LEAN_PRIMARY_TAIL>(pr, q, t)) {
                         // strict, and among equal t the lower list position: first index wins ties
                         if (t < nt || (t == nt && holder >= 0 && pos < holder)) {
                             nt = t;
@@ -1415,9 +1464,9 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
                         const float4 *lsorted = reinterpret_cast<const float4 *>(ax->lsorted[li]);
                         const int cb = lsorted ? build_list2<STATS, TABLDS, true, false, 1>(
                                                      tab, fc, n, mylist, mykeys, myblks, b, lane, st_cull, lsorted,
-                                                     reinterpret_cast<const float4 *>(ax->lblocks[li]))
+                                                     reinterpret_cast<const float4 *>(ax->lblocks[li]), nullptr, may_skip)
                                                : build_list2<STATS, TABLDS, true, false>(tab, fc, n, mylist, mykeys, myblks, b,
-                                                                                         lane, st_cull);
+                                                                                         lane, st_cull, nullptr, nullptr, nullptr, may_skip);
                         const int c = cb & 0x3fffffff;
                         if (may_skip && (cb & 0x40000000)) {
                             if (STATS == 1) hist[7] += 1;
@@ -1519,7 +1568,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
                         for (int e = 0; e < scount_j; ++e) {
                             const float4 nxt = entry_at<TABLDS>(s_use_list, mylist, tab, gtab,
                                                                 e + 1 < scount_j ? e + 1 : e);   // one entry in flight
-                            shadow_test(sr, cur, shadowed, force_slow);
+                            shadow_test<LEAN_SHADOW_TAIL>(sr, cur, shadowed, force_slow);
                             cur = nxt;
                             if (STATS == 1) { st_shadow += __popcll(__ballot(lit)); st_slots += 64; }
                             if (__all(shadowed)) break;
