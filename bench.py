@@ -292,7 +292,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
 
     extras = {}
-    if not args.no_extras:
+    if not args.no_extras and world == 1:
         # camera nudged every frame (kernel.cu:1727 `cam.Org.z += 0.1`, back and forth so the view stays
         # the workload's): the eye-cone table is rebuilt on the device for every frame
         def cam_at(j):                 # eight positions 0.1 apart, walked back and forth

@@ -52,7 +52,7 @@ struct RtLightDev {
     float r, g, b;
     float ux, uy, uz;   // pos / |pos| (beam axis for conservative shadow culling)
     float pos_len;      // |pos|
-    float pad_;
+    float fin;          // 1 if r, g and b are all finite, else 0
 };
 
 struct RtPlaneDev {     // plane: a point and the normal as given (kernel.cu:364-367)

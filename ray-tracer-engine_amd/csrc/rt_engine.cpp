@@ -855,6 +855,7 @@ static void rt_build_frame_aux(const rt_scene *s, RtFrameAux *ax)
         d.r = l.r; d.g = l.g; d.b = l.b;
         const float len = std::sqrt(l.pos.x * l.pos.x + l.pos.y * l.pos.y + l.pos.z * l.pos.z);
         d.pos_len = len;
+        d.fin = (std::isfinite(l.r) && std::isfinite(l.g) && std::isfinite(l.b)) ? 1.f : 0.f;
         // a light at the origin has no beam axis: NaN makes the kernel skip culling
         d.ux = len > 0 ? l.pos.x / len : NAN;
         d.uy = len > 0 ? l.pos.y / len : NAN;

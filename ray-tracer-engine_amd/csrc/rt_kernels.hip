@@ -1304,6 +1304,8 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
         }
 
         phase(3);
+        const bool tex_fin = (__builtin_fabsf(tr) < __builtin_inff()) & (__builtin_fabsf(tg) < __builtin_inff()) &
+                             (__builtin_fabsf(tb) < __builtin_inff());
         float fr = 0.f, fg = 0.f, fb = 0.f;   // this sample's colour (sky texel on a miss)
         if (sky_idx >= 0) {
             fr = ax->sky_r[sky_idx];
@@ -1377,8 +1379,9 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
                 bool zero_ok = false;   // brightness 0 adds exactly nothing for this lane
                 if (CULL && !force_slow) {
                     const float a0 = dot3(normal, toL);
-                    const float fin = (L.r * tr) * (L.g * tg) * (L.b * tb);   // finite iff all six are
-                    zero_ok = (__builtin_fabsf(fin) < __builtin_inff()) && (__builtin_fabsf(a0) < 1.0e30f);
+                    // (0 * l.r) * r is 0 iff the light's colour (frame constant, checked by the host) and the
+                    // texel (checked once per pixel) are finite
+                    zero_ok = tex_fin && (L.fin != 0.f) && (__builtin_fabsf(a0) < 1.0e30f);
                     const bool away = (a0 < -1.0e-4f) && zero_ok;
                     lit = inc && !away;
                     if (!__any(lit)) continue;
