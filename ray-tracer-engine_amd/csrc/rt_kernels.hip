@@ -348,12 +348,12 @@ __device__ __forceinline__ unsigned rgb_to_int(int r, int g, int b)
 // ---------------------------------------------------------------------------
 // sphere::intersect, kernel.cu:293-354, on a table entry {cx,cy,cz,radius*radius}
 // ---------------------------------------------------------------------------
-struct RayK {          // a ray plus the per-ray constants of the quadratic
+struct RayK {          // a ray plus the one per-ray constant of the quadratic that every test needs
     float ox, oy, oz;
     float dx, dy, dz;
-    float a2;          // 2*A
-    float a4;          // 4*A
-    float h_sure;      // h < -h_sure  =>  t >= RT_T_MIN for sure (see shadow loop)
+    float a4;          // 4*A (kernel.cu:334: B*B - 4*A*C)
+    // 2*A, the divisor of both roots, only where a root is actually formed (the same expression on the same operands)
+    __device__ __forceinline__ float a2() const { return 2.f * ((dx * dx + dy * dy) + dz * dz); }
 };
 
 __device__ __forceinline__ RayK make_ray(V3 o, V3 d)
@@ -362,9 +362,7 @@ __device__ __forceinline__ RayK make_ray(V3 o, V3 d)
     r.ox = o.x; r.oy = o.y; r.oz = o.z;
     r.dx = d.x; r.dy = d.y; r.dz = d.z;
     const float A = (d.x * d.x + d.y * d.y) + d.z * d.z;
-    r.a2 = 2.f * A;
     r.a4 = 4.f * A;
-    r.h_sure = 2.0e-4f * A;
     return r;
 }
 
@@ -388,10 +386,11 @@ __device__ __forceinline__ Quad quadratic(const RayK &r, float4 s)
 __device__ __forceinline__ bool intersect_tail(const RayK &r, const Quad &q, float &t)
 {
     const float sq = __builtin_sqrtf(q.disc);
-    t = (-q.B + sq) / r.a2;
+    const float a2 = r.a2();
+    t = (-q.B + sq) / a2;
     if (t == 0.f) return true;
     if (t >= RT_T_MIN) {
-        const float t2 = (-q.B - sq) / r.a2;
+        const float t2 = (-q.B - sq) / a2;
         if (t > t2) t = t2;
         return true;
     }
@@ -408,15 +407,15 @@ __device__ __forceinline__ bool intersect_tail_t(const RayK &r, const Quad &q, f
     if constexpr (!LEAN) {
         return intersect_tail(r, q, t);
     } else {
-        const float nb = -q.B;
-        const bool pre = (q.disc >= 0x1.0p-96f) & (q.disc <= 0x1.0p60f) & (r.a2 >= 0x1.0p-20f) & (r.a2 <= 0x1.0p20f);
+        const float nb = -q.B, a2 = r.a2();
+        const bool pre = (q.disc >= 0x1.0p-96f) & (q.disc <= 0x1.0p60f) & (a2 >= 0x1.0p-20f) & (a2 <= 0x1.0p20f);
         if (__builtin_expect(!pre, 0)) return intersect_tail(r, q, t);
         const float sq = lean_sqrt(q.disc);
         const float n1 = nb + sq, n2 = nb - sq;
         const bool safe = (__builtin_fminf(__builtin_fabsf(n1), __builtin_fabsf(n2)) >= 0x1.0p-40f) &
                           (__builtin_fmaxf(__builtin_fabsf(n1), __builtin_fabsf(n2)) <= 0x1.0p40f);
         if (__builtin_expect(!safe, 0)) return intersect_tail(r, q, t);
-        const LeanRcp ra(r.a2);
+        const LeanRcp ra(a2);
         t = ra.divide(n1);
         if (t >= RT_T_MIN) {           // t == 0 cannot happen here: |n1| >= 2^-40 and 2A <= 2^20
             const float t2 = ra.divide(n2);
@@ -913,7 +912,9 @@ __device__ __forceinline__ void shadow_test(const RayK &sr, float4 s, bool &shad
         need = !shadowed;
     } else {
         const bool cand = (q.disc >= 0.f) && !shadowed;
-        const bool sure = cand && (q.h < -sr.h_sure);
+        // h < -2e-4*A puts t above RT_T_MIN (-B >= 4e-4*A, sqrt(disc) >= 0, divided by 2A); 5e-5 * (4A) is that
+        // bound up to a rounding the strict margins of the argument swallow many times over
+        const bool sure = cand && (q.h < -5.0e-5f * sr.a4);
         const bool behind = (q.h > 0.f) && (q.disc < q.BB * RT_BEHIND_FACTOR);
         shadowed = shadowed || sure;
         need = cand && !sure && !behind;
@@ -1567,12 +1568,11 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
                     const int scount_j = RT_ABL(1) ? 0 : scount;
                     if (scount_j > 0) {
                         const float4 *gtab = CULL ? reinterpret_cast<const float4 *>(fc.sorted) : spheres;
-                        float4 cur = entry_at<TABLDS>(s_use_list, mylist, tab, gtab, 0);
+                        // (no entry kept in flight: at 7 waves per SIMD the LDS latency is covered by the other
+                        // waves, and the four registers are what lets the kernel run at 7)
                         for (int e = 0; e < scount_j; ++e) {
-                            const float4 nxt = entry_at<TABLDS>(s_use_list, mylist, tab, gtab,
-                                                                e + 1 < scount_j ? e + 1 : e);   // one entry in flight
+                            const float4 cur = entry_at<TABLDS>(s_use_list, mylist, tab, gtab, e);
                             shadow_test<LEAN_SHADOW_TAIL>(sr, cur, shadowed, force_slow);
-                            cur = nxt;
                             if (STATS == 1) { st_shadow += __popcll(__ballot(lit)); st_slots += 64; }
                             if (__all(shadowed)) break;
                         }
