@@ -200,6 +200,18 @@ typedef struct rt_launch_opts {
                                 memory / L2 and keeping only the tiles' survivor lists in LDS.
                                 Same pixels; measured slower, so opt-in.
                                 Default tile only; ignored when the table does not fit          */
+    int fast;                /* 1: opt-in APPROXIMATE mode. Everything that enters a pixel continuously
+                                (primary hit, normal, toL) stays exact; the ten shadow-sample
+                                directions of a light are built once per light in binary32 with
+                                hardware rsq / sqrt and FMAs (instead of following the reference's
+                                in-place re-normalisations in binary64 trigonometry), the shadow
+                                tests use FMAs and approximate roots, the texel index comes from the
+                                binary32 (tx, ty) without the certainty test. NOT bit-exact: a pixel
+                                is either identical or one where a discrete decision flipped (a
+                                shadow sample = 0.1 of a light's brightness, a neighbouring texel):
+                                about 2 pixels in 10^5 at C3. Never the
+                                default; culling kernels with the default tile and no mesh only --
+                                otherwise ignored (the launch is exact)                            */
 } rt_launch_opts;
 
 enum { RT_STAT_PRIMARY_TESTS = 0, /* sphere tests issued for primary rays (per lane) */

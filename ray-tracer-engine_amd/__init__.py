@@ -123,7 +123,7 @@ class LaunchOpts(C.Structure):
                 ("accumulate", C.c_int), ("resolve", C.c_int), ("cull", C.c_int), ("tile", C.c_int),
                 ("stats", C.c_void_p), ("force_slow_path", C.c_int), ("profile", C.c_int),
                 ("interleave_count", C.c_int), ("interleave_index", C.c_int), ("interleave_rows", C.c_int),
-                ("packed24", C.c_void_p), ("table_lds", C.c_int)]
+                ("packed24", C.c_void_p), ("table_lds", C.c_int), ("fast", C.c_int)]
 
 
 class FrameDesc(C.Structure):
@@ -383,7 +383,7 @@ class Scene:
 
     def frame_desc(self, width, height, *, pixels=0, rgba=0, cam=None, aspect=None, y0=0, y1=0, spp=1,
                    sample_base=0, sample_total=0, accumulate=False, resolve=0, cull=True, tile=0,
-                   stats=0, force_slow=False, profile=False, interleave=None, packed24=0, table_lds=False) -> FrameDesc:
+                   stats=0, force_slow=False, profile=False, interleave=None, packed24=0, table_lds=False, fast=False) -> FrameDesc:
         fd = FrameDesc()
         fd.struct_size = C.sizeof(FrameDesc)
         fd.width, fd.height = width, height
@@ -406,6 +406,7 @@ class Scene:
             o.interleave_count, o.interleave_index, o.interleave_rows = interleave
         o.packed24 = packed24
         o.table_lds = 1 if table_lds else 0
+        o.fast = 1 if fast else 0
         return fd
 
     def render_raw(self, fd: FrameDesc, stream=0):

@@ -1052,6 +1052,8 @@ int rt_frame_kernel_choice(const rt_scene *s, const rt_frame_desc *fd, RtKernelC
     kc->cull = (fd->opts.cull == 0) ? 0 : 1;
     kc->mode = fd->opts.stats ? (fd->opts.profile ? 3 : 1) : (fd->opts.force_slow_path ? 2 : 0);
     kc->feat = s->n_boxes > 0 ? 2 : ((s->n_planes > 0 || s->n_cubes > 0) ? 1 : 0);
+    // the opt-in approximate mode exists for the product configuration only; anything else renders exactly
+    if (fd->opts.fast == 1 && kc->mode == 0 && kc->cull && kc->tile == 8 && kc->feat < 2 && fd->opts.table_lds != 1) kc->mode = 4;
     // whole-table LDS staging (north_star's first design, measured slower: DESIGN.md section 3)
     // is opt-in per launch and only when the table fits next to the survivor lists
     kc->table_lds = (fd->opts.table_lds == 1 && s->n_spheres <= kMaxSpheresLds) ? 1 : 0;

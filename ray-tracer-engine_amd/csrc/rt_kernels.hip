@@ -200,11 +200,23 @@ struct LeanRcp {   // the divisor-only part of the division expansion
     }
 };
 
-template <bool LEAN>
+// PREC: 0 = the IEEE forms as hipcc expands them, 1 = lean (the same bits, see above), 2 = FAST: the opt-in
+// approximate mode of rt_launch_opts.fast (hardware reciprocal square root / reciprocal / square root,
+// binary32 trigonometry, FMA contraction) -- NOT bit-exact; north_star's tolerance is 1e-5 relative per
+// channel away from the discrete decisions (a shadow sample, a texel, a silhouette), see DESIGN.md section 4c.
+template <int PREC>
 __device__ __forceinline__ V3 normalise_t(V3 &v)
 {
-    if constexpr (!LEAN) {
+    if constexpr (PREC == 0) {
         return normalise_inplace(v);
+    } else if constexpr (PREC == 2) {
+        const float d2 = __builtin_fmaf(v.x, v.x, __builtin_fmaf(v.y, v.y, v.z * v.z));
+        if (d2 > 0.f) {   // a zero vector stays as it is and (0,0,0) is returned, as normalise() does
+            const float inv = __builtin_amdgcn_rsqf(d2);
+            v.x *= inv; v.y *= inv; v.z *= inv;
+            return v;
+        }
+        return V3{0.f, 0.f, 0.f};
     } else {
         const float d2 = dot3(v, v);
         const float amin = __builtin_fminf(__builtin_fminf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), __builtin_fabsf(v.z));
@@ -382,6 +394,19 @@ __device__ __forceinline__ Quad quadratic(const RayK &r, float4 s)
     return q;
 }
 
+// FAST mode: the same quadratic with fused multiply-adds (11 instructions instead of 17)
+__device__ __forceinline__ Quad quadratic_fast(const RayK &r, float4 s)
+{
+    const float ocx = r.ox - s.x, ocy = r.oy - s.y, ocz = r.oz - s.z;
+    Quad q;
+    q.h = __builtin_fmaf(r.dx, ocx, __builtin_fmaf(r.dy, ocy, r.dz * ocz));
+    q.B = 2.f * q.h;
+    const float C = __builtin_fmaf(ocx, ocx, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocz, ocz, -s.w)));
+    q.BB = q.B * q.B;
+    q.disc = __builtin_fmaf(-r.a4, C, q.BB);
+    return q;
+}
+
 // The tail of intersect once B and the discriminant are known.
 __device__ __forceinline__ bool intersect_tail(const RayK &r, const Quad &q, float &t)
 {
@@ -401,11 +426,22 @@ __device__ __forceinline__ bool intersect_tail(const RayK &r, const Quad &q, flo
 // divide by the same 2A, so the divisor's part of the expansion is shared). Safe range, per lane:
 // disc in [2^-96, 2^60], 2A in [2^-20, 2^20], both numerators between 2^-40 and 2^40 in magnitude --
 // anything else (a zero numerator in particular: the reference's `t == 0` clause) takes the IEEE forms.
-template <bool LEAN>
+template <int PREC>
 __device__ __forceinline__ bool intersect_tail_t(const RayK &r, const Quad &q, float &t)
 {
-    if constexpr (!LEAN) {
+    if constexpr (PREC == 0) {
         return intersect_tail(r, q, t);
+    } else if constexpr (PREC == 2) {
+        const float sq = __builtin_amdgcn_sqrtf(q.disc);
+        const float inv = __builtin_amdgcn_rcpf(r.a2());
+        t = (-q.B + sq) * inv;
+        if (t == 0.f) return true;
+        if (t >= RT_T_MIN) {
+            const float t2 = (-q.B - sq) * inv;
+            if (t > t2) t = t2;
+            return true;
+        }
+        return false;
     } else {
         const float nb = -q.B, a2 = r.a2();
         const bool pre = (q.disc >= 0x1.0p-96f) & (q.disc <= 0x1.0p60f) & (a2 >= 0x1.0p-20f) & (a2 <= 0x1.0p20f);
@@ -794,13 +830,53 @@ __device__ __forceinline__ int build_box_list(const float4 *__restrict__ bsph, i
 // ---------------------------------------------------------------------------
 // castLightRay's sample construction, kernel.cu:1438-1468 (exact)
 // ---------------------------------------------------------------------------
-template <bool LEAN>
+template <int LEAN>
 struct ShadowChain {
     V3 toL;            // keeps being re-normalised in place by the reference
     bool stable;       // an iteration leaves toL as it found it: every later iteration repeats this one
     bool fixed1;       // normalise() maps toL to itself: later iterations can only differ in `angle`
     float angle;
     float m00, m01, m02, m10, m11, m12, m20, m21, m22;
+
+    // FAST mode: toL itself is exact -- begin() and settle() run as in the exact kernel, because toL
+    // multiplies the brightness continuously (kernel.cu:1541) -- but everything that only shapes the
+    // sample directions (the angle to the light's edge, the rotation axis, angle and matrix of
+    // kernel.cu:1444-1466) is computed ONCE per light from the settled toL, in binary32 with hardware
+    // rsq / sqrt and fused multiply-adds, instead of being followed through the ten iterations.
+    __device__ __forceinline__ void setup_fast(const RtLightDev &L, V3 start)
+    {
+        const V3 lpos{L.px, L.py, L.pz};
+        const V3 P{-toL.z, 0.f, toL.x};                                     // cross(toL, (0,1,0))
+        V3 e0{__builtin_fmaf(P.x, L.size, lpos.x) - start.x, lpos.y - start.y, __builtin_fmaf(P.z, L.size, lpos.z) - start.z};
+        const V3 toEdge = normalise_t<2>(e0);
+        angle = __builtin_cosf(2.f * __builtin_fmaf(toL.x, toEdge.x, __builtin_fmaf(toL.y, toEdge.y, toL.z * toEdge.z)));
+        V3 ax0{-toL.y, toL.x, 0.f};                                         // cross((0,0,1), toL)
+        const V3 axis = normalise_t<2>(ax0);
+        const float cs = toL.z;                                             // cos(acos(toL.z))
+        const float sn = __builtin_amdgcn_sqrtf(__builtin_fmaxf(__builtin_fmaf(-cs, cs, 1.f), 0.f));
+        const float omc = 1.f - cs;
+        m00 = __builtin_fmaf(axis.x, axis.x, cs);
+        m01 = axis.x * axis.y * omc;
+        m02 = -axis.y * sn;
+        m10 = m01;
+        m11 = __builtin_fmaf(axis.y * axis.y, omc, cs);
+        m12 = -axis.x * sn;
+        m20 = -axis.y * sn;
+        m21 = axis.x * sn;
+        m22 = cs;
+        stable = true;
+        fixed1 = true;
+    }
+    __device__ __forceinline__ V3 direction_fast(AuxPtr ax, const RtLightDev &L, int j)
+    {
+        const float z = __builtin_fmaf(ax->jf[j], 1.0f - angle, angle);
+        const float sq = __builtin_amdgcn_sqrtf(__builtin_fmaf(-z, z, 1.f));   // NaN beyond |z| = 1, as the exact form
+        const float x = sq * ax->jcos[j], y = sq * ax->jsin[j];
+        V3 nd{L.px - __builtin_fmaf(x, m00, __builtin_fmaf(y, m10, z * m20)),
+              L.py - __builtin_fmaf(x, m01, __builtin_fmaf(y, m11, z * m21)),
+              L.pz - __builtin_fmaf(x, m02, __builtin_fmaf(y, m12, z * m22))};
+        return normalise_t<2>(nd);
+    }
 
     __device__ __forceinline__ void begin(V3 lpos, V3 start)
     {
@@ -903,10 +979,10 @@ struct ShadowChain {
 // kernel.cu:1504-1508). Two shortcuts decide most entries without sqrt/div:
 // h < -h_sure puts t above RT_T_MIN (-B >= 2*h_sure and sqrt(disc) >= 0), and
 // "behind" (see RT_BEHIND_FACTOR) makes t strictly negative.
-template <bool LEAN = false>
+template <int LEAN = 0>
 __device__ __forceinline__ void shadow_test(const RayK &sr, float4 s, bool &shadowed, bool force_slow)
 {
-    const Quad q = quadratic(sr, s);
+    const Quad q = (LEAN == 2) ? quadratic_fast(sr, s) : quadratic(sr, s);
     bool need;
     if (force_slow) {
         need = !shadowed;
@@ -945,26 +1021,27 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
 {
     constexpr int STATS = (MODE == 1) ? 1 : (MODE == 3) ? 2 : 0;
     constexpr bool force_slow = (MODE == 2);
+    constexpr bool FAST = (MODE == 4);    // rt_launch_opts.fast: approximate arithmetic, never the default
     constexpr bool MESH = (FEAT == 2);
     constexpr bool PRIMS = (FEAT >= 1);   // cubes and planes may be present
     // the culling kernels take every exactness-preserving shortcut (lean normalise/sqrt, fast
     // texel index); the brute-force and force-slow ones evaluate everything the long way
 #ifdef RT_NO_LEAN
-    constexpr bool LEAN = false;
+    constexpr int LEAN = 0;
 #else
-    constexpr bool LEAN = CULL && !force_slow;
+    constexpr int LEAN = (CULL && !force_slow) ? 1 : 0;   // precision class of normalise_t & co. (FAST: primary rays, normal and toL stay exact)
 #endif
     // the lean tail of intersect(): for the primary rays; for the shadow rays it costs the one-sample
     // kernel two spilled registers at its 6-waves-per-SIMD budget (measured: profiles/r02_variants.txt)
 #ifdef RT_NO_LEAN_PRIMARY_TAIL
-    constexpr bool LEAN_PRIMARY_TAIL = false;
+    constexpr int LEAN_PRIMARY_TAIL = 0;
 #else
-    constexpr bool LEAN_PRIMARY_TAIL = LEAN;
+    constexpr int LEAN_PRIMARY_TAIL = LEAN;
 #endif
 #ifdef RT_LEAN_SHADOW_TAIL
-    constexpr bool LEAN_SHADOW_TAIL = LEAN;
+    constexpr int LEAN_SHADOW_TAIL = LEAN;
 #else
-    constexpr bool LEAN_SHADOW_TAIL = false;
+    constexpr int LEAN_SHADOW_TAIL = FAST ? 2 : 0;
 #endif
     constexpr int TH = 64 / TW;
     // Waves per workgroup: RT_WAVES_PER_WG share one staged table (TABLDS); with the table left
@@ -1234,8 +1311,16 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
             V3 nrm{hp.x - sk.x, hp.y - sk.y, hp.z - sk.z};
             normalise_t<LEAN>(nrm);
             const int sky_w = ax->sky_w, sky_h = ax->sky_h;
-            const int ix = f2i((1.f + rtm::atan2f_rt(nrm.z, nrm.x, myatan) / 3.1415f) * 0.5f * (float)sky_w);
-            const int iy = f2i(rtm::acosf_rt(nrm.y, myatan) / 3.1415f * (float)sky_h);
+            int ix, iy;
+            if (FAST) {
+                float ux, uy;
+                approx_sphere_uv(nrm, ux, uy);
+                ix = f2i(ux * (float)sky_w);
+                iy = f2i(uy * (float)sky_h);
+            } else {
+                ix = f2i((1.f + rtm::atan2f_rt(nrm.z, nrm.x, myatan) / 3.1415f) * 0.5f * (float)sky_w);
+                iy = f2i(rtm::acosf_rt(nrm.y, myatan) / 3.1415f * (float)sky_h);
+            }
             int idx = iy * sky_w + ix;
             const int last = sky_w * sky_h - 1;
             idx = idx < 0 ? 0 : (idx > last ? last : idx);   // documented clamp (reference is UB there)
@@ -1277,6 +1362,8 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
                 normalise_t<LEAN>(normal);
                 if (RT_ABL(8)) {
                     tx = normal.x; ty = normal.y;
+                } else if (FAST) {
+                    approx_sphere_uv(normal, tx, ty);   // no certainty test: a texel now and then is the neighbour
                 } else if (LEAN && !RT_ABL(4096)) {
                     float ux, uy;
                     approx_sphere_uv(normal, ux, uy);
@@ -1558,9 +1645,15 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
                     if (lane < scount) mylist[rank] = e;
                     wave_lds_sync();
                 }
+                if (FAST && !all_clear) {   // toL as the reference leaves it (exact), then the sample frame once, approximately
+                    chain.settle();
+                    chain.setup_fast(L, start);
+                }
 #pragma unroll 1
                 for (int j = 0; j < (all_clear ? 0 : RT_SHADOW_SAMPLES); ++j) {
-                    const V3 new_dir = RT_ABL(2) ? chain.toL : chain.direction(ax, force_slow, L, start, j, myatan);
+                    const V3 new_dir = RT_ABL(2) ? chain.toL
+                                       : FAST   ? chain.direction_fast(ax, L, j)
+                                                : chain.direction(ax, force_slow, L, start, j, myatan);
                     const RayK sr = make_ray(start, new_dir);
                     phase(6);
                     // any-hit over the list, kernel.cu:1501-1510
@@ -1900,6 +1993,10 @@ static RtTraceFn trace_fn_mode_feat(int mode, int feat)
     case 0: return feat ? rt_trace_tiles<TW, CULL, 0, TABLDS, 1, MULTI> : rt_trace_tiles<TW, CULL, 0, TABLDS, 0, MULTI>;
     case 1: return feat ? rt_trace_tiles<TW, CULL, 1, TABLDS, 1, MULTI> : rt_trace_tiles<TW, CULL, 1, TABLDS, 0, MULTI>;
     case 2: return feat ? rt_trace_tiles<TW, CULL, 2, TABLDS, 1, MULTI> : rt_trace_tiles<TW, CULL, 2, TABLDS, 0, MULTI>;
+    case 4:   // fast mode: the default tile, culling on, table in global memory
+        if constexpr (TW == 8 && CULL && !TABLDS)
+            return feat ? rt_trace_tiles<TW, CULL, 4, TABLDS, 1, MULTI> : rt_trace_tiles<TW, CULL, 4, TABLDS, 0, MULTI>;
+        return nullptr;
 #ifdef RT_TUNING
     case 3: return feat ? rt_trace_tiles<TW, CULL, 3, TABLDS, 1, MULTI> : rt_trace_tiles<TW, CULL, 3, TABLDS, 0, MULTI>;
 #endif
@@ -1941,7 +2038,7 @@ extern "C" hipError_t rt_dev_prepare(void)
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorNoDevice;
     if (dev < 64 && ((done >> dev) & 1ull)) return hipSuccess;
     for (int cull = 0; cull < 2; ++cull)
-        for (int mode = 0; mode < 4; ++mode)
+        for (int mode = 0; mode < 5; ++mode)
             for (int feat = 0; feat < 3; ++feat)
                 for (int multi = 0; multi < 2; ++multi) {
                     const RtTraceFn fn = trace_fn(8, cull, mode, 1, feat, multi);

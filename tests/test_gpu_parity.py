@@ -791,3 +791,27 @@ def test_root_side_assembly_kernel(rt, gpu, world):
     frame = root.assemble()
     torch.cuda.synchronize()
     assert torch.equal(frame, want)
+
+
+def test_fast_mode_stays_within_the_tolerance_away_from_flips(rt, gpu):
+    """rt_launch_opts.fast (opt-in, approximate sample construction / shadow tests / texel coordinates):
+    everything that enters a pixel continuously -- primary hit, normal, toL -- stays exact, so against the
+    exact frame (= the oracle's) a pixel is either bit-identical or one where a discrete decision went the
+    other way (a shadow sample: 0.1 of a light's brightness; a neighbouring texel), and those are a few in
+    10^5. north_star's tolerance (1e-5 relative per channel) holds on every other pixel with error 0.
+    Never the default: the same call without the flag is bit-exact, and configurations the mode does not
+    cover (brute force, other tiles, the work counters, ...) ignore the flag and stay exact."""
+    w, h, n = 960, 540, 1024
+    scene = Inputs(rt, n).scene()
+    e, pe, _ = _render(scene, w, h)
+    f, pf, _ = _render(scene, w, h, fast=True)
+    rel = np.abs(f[..., :3].astype(np.float64) - e[..., :3]) / np.maximum(np.abs(e[..., :3]), 1e-3)
+    worst = rel.max(axis=2)
+    flipped = worst > 1e-5
+    assert flipped.mean() < 3e-4, flipped.mean()
+    assert (worst[~flipped] == 0).all()                  # not flipped = not touched
+    assert np.array_equal(pe[~flipped], pf[~flipped])
+    assert (pe == pf).mean() > 0.9997
+    for kw in (dict(cull=False), dict(tile=16), dict(want_stats=True), dict(force_slow=True), dict(table_lds=True)):
+        g, pg, _ = _render(scene, w, h, fast=True, **kw)
+        assert np.array_equal(_bits(g), _bits(e)) and np.array_equal(pg, pe), kw

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""The opt-in approximate mode (rt_launch_opts.fast) against the exact kernel -- which equals the oracle
+bit for bit -- on the headline configuration: time per frame, relative error per channel, and the
+fraction of pixels where a discrete decision (a shadow sample, a texel, a silhouette) went the other way.
+north_star's tolerance is 1e-5 relative per channel; BASELINE.md asks for the flipped fraction separately."""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, rt_amd
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--width", type=int, default=3840)
+ap.add_argument("--height", type=int, default=2160)
+ap.add_argument("--spheres", type=int, default=1024)
+ap.add_argument("--steps", type=int, default=100)
+a = ap.parse_args()
+rt = rt_amd.load()
+scene = rt.Scene.default(a.spheres)
+w, h = a.width, a.height
+
+
+def timed(fast):
+    rgba = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    pk = torch.empty((h, w), dtype=torch.int32, device="cuda")
+    fd = scene.frame_desc(w, h, pixels=pk.data_ptr(), rgba=rgba.data_ptr(), fast=fast)
+    st = torch.cuda.current_stream()
+    for _ in range(10):
+        scene.render_raw(fd, st.cuda_stream)
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        scene.render_raw(fd, st.cuda_stream)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / a.steps * 1e3, rgba.cpu().numpy()[..., :3], pk.cpu().numpy().view(np.uint32)
+
+
+ms_e, e, pe = timed(False)
+ms_f, f, pf = timed(True)
+rel = np.abs(f.astype(np.float64) - e) / np.maximum(np.abs(e), 1e-3)
+worst = rel.max(axis=2)
+n = worst.size
+flipped = worst > 1e-5
+out = {
+    "config": f"{w}x{h}, {a.spheres} spheres, 1 spp, static camera, one frame at a time",
+    "exact_ms": ms_e, "fast_ms": ms_f, "fast_Mrays_per_s": w * h / ms_f / 1e3, "speedup": ms_e / ms_f,
+    "pixels": int(n),
+    "bit_identical_fraction": float((worst == 0).sum() / n),
+    "within_1e-6_fraction": float((worst <= 1e-6).sum() / n),
+    "within_1e-5_fraction": float((worst <= 1e-5).sum() / n),
+    "flipped_fraction": float(flipped.sum() / n),
+    "max_rel_error_on_non_flipped": float(worst[~flipped].max()),
+    "flipped_abs_error_percentiles_50_90_99": [float(v) for v in np.percentile(np.abs(f - e).max(axis=2)[flipped], [50, 90, 99])] if flipped.any() else [],
+    "packed_words_equal_fraction": float((pe == pf).sum() / n),
+    "note": "relative error per channel against the exact kernel (= the oracle), denominator max(|exact|, 1e-3); "
+            "flipped = beyond north_star's 1e-5: a shadow sample (0.1 of a light's brightness), a neighbouring texel, a silhouette pixel",
+}
+print(json.dumps(out, indent=1))
