@@ -113,6 +113,8 @@ struct RtFrameAux {
     const float *box_spheres;   // float4 per leaf: bounding sphere {cx,cy,cz,r^2} for beam culling (+ blocks of leaves)
     const float *tri9;          // the three vertices (9 floats) of every (leaf, triangle) pair in the order of
                                 // tri_idx: a leaf's triangles are contiguous, one coalesced load stages 7 of them
+    const float *tri_bs;        // float4 per (leaf, triangle) pair, same order: bounding sphere {centre, radius} of
+                                // the triangle for the per-triangle beam cull; radius +inf = never culled
 };
 
 enum {                          // RtFrameConsts::flags

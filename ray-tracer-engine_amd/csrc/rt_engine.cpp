@@ -161,6 +161,7 @@ struct rt_scene {
     int *d_tri_idx = nullptr;
     float *d_box_spheres = nullptr;
     float *d_tri9 = nullptr;
+    float *d_tri_bs = nullptr;
     int n_boxes = 0, n_tris = 0, mesh_has_normals = 0;
     // per-light column blocks (see RtFrameAux::lsorted): one allocation, rebuilt when the
     // sphere list or a light's position changes
@@ -272,6 +273,7 @@ extern "C" void rt_scene_destroy(rt_scene *s)
     if (s->d_tri_idx) (void)hipFree(s->d_tri_idx);
     if (s->d_box_spheres) (void)hipFree(s->d_box_spheres);
     if (s->d_tri9) (void)hipFree(s->d_tri9);
+    if (s->d_tri_bs) (void)hipFree(s->d_tri_bs);
     if (s->d_light_tabs) (void)hipFree(s->d_light_tabs);
     for (ConeSlot &c : s->cones) {
         if (c.buf) (void)hipFree(c.buf);
@@ -586,7 +588,9 @@ extern "C" int rt_scene_set_mesh(rt_scene *s, const rt_mesh *mesh)
     if (s->d_tri_idx) RT_HIP(hipFree(s->d_tri_idx));
     if (s->d_box_spheres) RT_HIP(hipFree(s->d_box_spheres));
     if (s->d_tri9) RT_HIP(hipFree(s->d_tri9));
+    if (s->d_tri_bs) RT_HIP(hipFree(s->d_tri_bs));
     s->d_tri9 = nullptr;
+    s->d_tri_bs = nullptr;
     s->d_tris = nullptr; s->d_boxes = nullptr; s->d_tri_idx = nullptr; s->d_box_spheres = nullptr;
     s->n_boxes = s->n_tris = 0;
     if (!mesh || mesh->bvhbox_count == 0) return RT_OK;
@@ -678,6 +682,38 @@ extern "C" int rt_scene_set_mesh(rt_scene *s, const rt_mesh *mesh)
         }
         RT_HIP(hipMalloc((void **)&s->d_tri9, sizeof(float) * t9.size()));
         RT_HIP(hipMemcpy(s->d_tri9, t9.data(), sizeof(float) * t9.size(), hipMemcpyHostToDevice));
+        // bounding sphere of every (leaf, triangle) pair for the per-triangle beam cull (beam_keeps_triangle):
+        // centre = centroid, radius = farthest vertex, rounded up; ill-shaped triangles (a corner sine below
+        // 0.1, or anything non-finite) get radius +inf and are never culled
+        std::vector<float> bs(idx.size() * 4 + 4 * 64, 0.f);
+        for (size_t k = 0; k < idx.size(); ++k) {
+            const float *p = &t9[9 * k];
+            double c[3], r = 0, e[3][3], len[3];
+            for (int a = 0; a < 3; ++a) c[a] = ((double)p[a] + p[3 + a] + p[6 + a]) / 3.0;
+            for (int v = 0; v < 3; ++v) {
+                double d2 = 0;
+                for (int a = 0; a < 3; ++a) d2 += ((double)p[3 * v + a] - c[a]) * ((double)p[3 * v + a] - c[a]);
+                r = std::max(r, std::sqrt(d2));
+            }
+            for (int v = 0; v < 3; ++v) {   // edge v: from vertex v to vertex (v+1)%3
+                len[v] = 0;
+                for (int a = 0; a < 3; ++a) {
+                    e[v][a] = (double)p[3 * ((v + 1) % 3) + a] - p[3 * v + a];
+                    len[v] += e[v][a] * e[v][a];
+                }
+                len[v] = std::sqrt(len[v]);
+            }
+            const double cx = e[0][1] * e[1][2] - e[0][2] * e[1][1], cy = e[0][2] * e[1][0] - e[0][0] * e[1][2],
+                         cz = e[0][0] * e[1][1] - e[0][1] * e[1][0];
+            const double area2 = std::sqrt(cx * cx + cy * cy + cz * cz);   // |e0 x e1| = twice the area
+            double min_sin = INFINITY;
+            for (int v = 0; v < 3; ++v) min_sin = std::min(min_sin, area2 / (len[v] * len[(v + 2) % 3]));
+            const bool good = std::isfinite(r) && std::isfinite(c[0] + c[1] + c[2]) && min_sin >= 0.1 && min_sin == min_sin;
+            bs[4 * k + 0] = (float)c[0]; bs[4 * k + 1] = (float)c[1]; bs[4 * k + 2] = (float)c[2];
+            bs[4 * k + 3] = good ? (float)(r * 1.001 + 1e-6) : INFINITY;
+        }
+        RT_HIP(hipMalloc((void **)&s->d_tri_bs, sizeof(float) * bs.size()));
+        RT_HIP(hipMemcpy(s->d_tri_bs, bs.data(), sizeof(float) * bs.size(), hipMemcpyHostToDevice));
     }
     s->n_boxes = mesh->bvhbox_count;
     s->n_tris = mesh->poly_count;
@@ -884,6 +920,7 @@ static void rt_build_frame_aux(const rt_scene *s, RtFrameAux *ax)
     ax->tri_idx = s->d_tri_idx;
     ax->box_spheres = s->d_box_spheres;
     ax->tri9 = s->d_tri9;
+    ax->tri_bs = s->d_tri_bs;
 }
 
 // Bring the device copy of RtFrameAux up to date (a camera move never changes it).
