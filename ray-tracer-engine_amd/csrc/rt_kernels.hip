@@ -1338,22 +1338,35 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
             const float4 sk = make_float4(ax->sky_cx, ax->sky_cy, ax->sky_cz, ax->sky_r2);
             const Quad q = quadratic(pr, sk);
             float t;
-            intersect_tail(pr, q, t);   // the boolean is ignored there, t is used as left
+            intersect_tail_t<LEAN_PRIMARY_TAIL>(pr, q, t);   // the boolean is ignored there, t is used as left
             const V3 hp{O.x + D.x * t, O.y + D.y * t, O.z + D.z * t};
             V3 nrm{hp.x - sk.x, hp.y - sk.y, hp.z - sk.z};
             normalise_t<LEAN>(nrm);
             const int sky_w = ax->sky_w, sky_h = ax->sky_h;
             int ix, iy;
+            int sky_fast = -1;
             if (FAST) {
                 float ux, uy;
                 approx_sphere_uv(nrm, ux, uy);
                 ix = f2i(ux * (float)sky_w);
                 iy = f2i(uy * (float)sky_h);
             } else {
-                ix = f2i((1.f + rtm::atan2f_rt(nrm.z, nrm.x, myatan) / 3.1415f) * 0.5f * (float)sky_w);
-                iy = f2i(rtm::acosf_rt(nrm.y, myatan) / 3.1415f * (float)sky_h);
+                if (LEAN) {
+                    // the same certainty test as for the object texture (approx_sphere_uv / sure_texel above); here
+                    // the exact expressions are binary32 chains of their own -- atan2f and acosf rounded to float, a
+                    // float division, 1.f + ..., two products -- which stay within 1.7e-7 of the real value, so the
+                    // margin is size * (1e-6 + 2^-22): 5e-7 approximation budget + that + both product roundings
+                    float ux, uy;
+                    approx_sphere_uv(nrm, ux, uy);
+                    sky_fast = sure_texel(ux, uy, sky_w, sky_h, ax->sky_mu_x, ax->sky_mu_y);
+                }
+                ix = iy = 0;
+                if (__builtin_expect(sky_fast < 0, 0)) {
+                    ix = f2i((1.f + rtm::atan2f_rt(nrm.z, nrm.x, myatan) / 3.1415f) * 0.5f * (float)sky_w);
+                    iy = f2i(rtm::acosf_rt(nrm.y, myatan) / 3.1415f * (float)sky_h);
+                }
             }
-            int idx = iy * sky_w + ix;
+            int idx = sky_fast >= 0 ? sky_fast : iy * sky_w + ix;
             const int last = sky_w * sky_h - 1;
             idx = idx < 0 ? 0 : (idx > last ? last : idx);   // documented clamp (reference is UB there)
             sky_idx = idx;
@@ -1982,6 +1995,14 @@ __global__ void rt_dbg_shortcuts(int what, unsigned seed, long long n, unsigned 
             if (cf >= 0) {
                 accepted += 1;
                 if (cf != f2i(ty * (float)hh) * w + f2i(tx * (float)w)) wrong += 1;
+            }
+            // the sky's own (binary32) expressions, kernel.cu:1157-1158, at 2048 x 1024 with its wider margin
+            const int sw = 2048, sh = 1024;
+            const int cs = sure_texel(ux, uy, sw, sh, (float)sw * (1.0e-6f + 0x1.0p-22f) * 1.01f, (float)sh * (1.0e-6f + 0x1.0p-22f) * 1.01f);
+            if (cs >= 0) {
+                const int ix = f2i((1.f + rtm::atan2f_rt(nrm.z, nrm.x, atab) / 3.1415f) * 0.5f * (float)sw);
+                const int iy = f2i(rtm::acosf_rt(nrm.y, atab) / 3.1415f * (float)sh);
+                if (cs != iy * sw + ix) wrong += 1;
             }
         }
     }
