@@ -1123,6 +1123,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
                        st_overflow = 0, st_hits = 0, st_unshadowed = 0, st_clusters = 0;
 
     unsigned long long hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_walks = 0, st_walks_no_penumbra = 0, st_pen_lanes = 0, st_walk_lanes = 0;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = 0;
     const bool span_only = RT_ABL(512);   // no inner stamps: near-real wave durations
@@ -1762,6 +1763,13 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
                     phase(7);
                 }
                 if (CULL) wave_lds_sync();
+                if (STATS == 1 && !all_clear) {   // how many of the walked lights had a lane in a penumbra at all
+                    const bool pen = lit && unshadowed != 0 && unshadowed != RT_SHADOW_SAMPLES;
+                    st_walks += 1;
+                    st_walks_no_penumbra += __any(pen) ? 0 : 1;
+                    st_pen_lanes += (unsigned long long)__popcll(__ballot(pen));
+                    st_walk_lanes += (unsigned long long)__popcll(__ballot(lit));
+                }
 
                 if (lit) {   // unlit lanes would add (0 * l.r) * r = +0
                     // b after `unshadowed` float+=double steps, then b *= max(normal.toL, 0)
@@ -1856,6 +1864,10 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
             atomicAdd(&fc.stats[6], st_entries);
             atomicAdd(&fc.stats[7], st_overflow);
             for (int k = 0; k < 8; ++k) atomicAdd(&fc.stats[8 + k], hist[k]);
+            atomicAdd(&fc.stats[17], st_walks);               // (slots 17.. hold the wave-duration histogram in MODE 3)
+            atomicAdd(&fc.stats[18], st_walks_no_penumbra);
+            atomicAdd(&fc.stats[19], st_pen_lanes);
+            atomicAdd(&fc.stats[20], st_walk_lanes);
             atomicAdd(&fc.stats[16], st_clusters);
         }
     }
