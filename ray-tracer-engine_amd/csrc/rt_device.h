@@ -115,6 +115,8 @@ struct RtFrameAux {
                                 // tri_idx: a leaf's triangles are contiguous, one coalesced load stages 7 of them
     const float *tri_bs;        // float4 per (leaf, triangle) pair, same order: bounding sphere {centre, radius} of
                                 // the triangle for the per-triangle beam cull; radius +inf = never culled
+    const float *tri_nrm;       // float4 per pair, same order: the triangle's unit normal (a beam that grazes the
+                                // triangle's plane never culls it, see beam_keeps_triangle)
 };
 
 enum {                          // RtFrameConsts::flags

@@ -162,6 +162,7 @@ struct rt_scene {
     float *d_box_spheres = nullptr;
     float *d_tri9 = nullptr;
     float *d_tri_bs = nullptr;
+    float *d_tri_nrm = nullptr;
     int n_boxes = 0, n_tris = 0, mesh_has_normals = 0;
     // per-light column blocks (see RtFrameAux::lsorted): one allocation, rebuilt when the
     // sphere list or a light's position changes
@@ -274,6 +275,7 @@ extern "C" void rt_scene_destroy(rt_scene *s)
     if (s->d_box_spheres) (void)hipFree(s->d_box_spheres);
     if (s->d_tri9) (void)hipFree(s->d_tri9);
     if (s->d_tri_bs) (void)hipFree(s->d_tri_bs);
+    if (s->d_tri_nrm) (void)hipFree(s->d_tri_nrm);
     if (s->d_light_tabs) (void)hipFree(s->d_light_tabs);
     for (ConeSlot &c : s->cones) {
         if (c.buf) (void)hipFree(c.buf);
@@ -589,6 +591,8 @@ extern "C" int rt_scene_set_mesh(rt_scene *s, const rt_mesh *mesh)
     if (s->d_box_spheres) RT_HIP(hipFree(s->d_box_spheres));
     if (s->d_tri9) RT_HIP(hipFree(s->d_tri9));
     if (s->d_tri_bs) RT_HIP(hipFree(s->d_tri_bs));
+    if (s->d_tri_nrm) RT_HIP(hipFree(s->d_tri_nrm));
+    s->d_tri_nrm = nullptr;
     s->d_tri9 = nullptr;
     s->d_tri_bs = nullptr;
     s->d_tris = nullptr; s->d_boxes = nullptr; s->d_tri_idx = nullptr; s->d_box_spheres = nullptr;
@@ -683,9 +687,11 @@ extern "C" int rt_scene_set_mesh(rt_scene *s, const rt_mesh *mesh)
         RT_HIP(hipMalloc((void **)&s->d_tri9, sizeof(float) * t9.size()));
         RT_HIP(hipMemcpy(s->d_tri9, t9.data(), sizeof(float) * t9.size(), hipMemcpyHostToDevice));
         // bounding sphere of every (leaf, triangle) pair for the per-triangle beam cull (beam_keeps_triangle):
-        // centre = centroid, radius = farthest vertex, rounded up; ill-shaped triangles (a corner sine below
-        // 0.1, or anything non-finite) get radius +inf and are never culled
+        // centre = centroid, radius = farthest vertex, rounded up; with it the unit normal and kappa, the least
+        // |cos| between a ray and the normal for which the cull is valid (slivers and anything non-finite: radius
+        // +inf, normal 0, kappa 2 -- never culled)
         std::vector<float> bs(idx.size() * 4 + 4 * 64, 0.f);
+        std::vector<float> bn(idx.size() * 4 + 4 * 64, 0.f);   // unit normals (zero = "always edge-on" for degenerate ones)
         for (size_t k = 0; k < idx.size(); ++k) {
             const float *p = &t9[9 * k];
             double c[3], r = 0, e[3][3], len[3];
@@ -708,12 +714,22 @@ extern "C" int rt_scene_set_mesh(rt_scene *s, const rt_mesh *mesh)
             const double area2 = std::sqrt(cx * cx + cy * cy + cz * cz);   // |e0 x e1| = twice the area
             double min_sin = INFINITY;
             for (int v = 0; v < 3; ++v) min_sin = std::min(min_sin, area2 / (len[v] * len[(v + 2) % 3]));
-            const bool good = std::isfinite(r) && std::isfinite(c[0] + c[1] + c[2]) && min_sin >= 0.1 && min_sin == min_sin;
+            // kappa = 3e-3 / (smallest corner sine), see beam_keeps_triangle; >= 1 means "never culled"
+            const bool good = std::isfinite(r) && std::isfinite(c[0] + c[1] + c[2]) && min_sin > 3.0e-3 && min_sin == min_sin &&
+                              area2 > 0 && std::isfinite(area2);
             bs[4 * k + 0] = (float)c[0]; bs[4 * k + 1] = (float)c[1]; bs[4 * k + 2] = (float)c[2];
             bs[4 * k + 3] = good ? (float)(r * 1.001 + 1e-6) : INFINITY;
+            if (good) {
+                bn[4 * k + 0] = (float)(cx / area2); bn[4 * k + 1] = (float)(cy / area2); bn[4 * k + 2] = (float)(cz / area2);
+                bn[4 * k + 3] = (float)(3.0e-3 / min_sin * 1.001);
+            } else {
+                bn[4 * k + 3] = 2.f;
+            }
         }
         RT_HIP(hipMalloc((void **)&s->d_tri_bs, sizeof(float) * bs.size()));
         RT_HIP(hipMemcpy(s->d_tri_bs, bs.data(), sizeof(float) * bs.size(), hipMemcpyHostToDevice));
+        RT_HIP(hipMalloc((void **)&s->d_tri_nrm, sizeof(float) * bn.size()));
+        RT_HIP(hipMemcpy(s->d_tri_nrm, bn.data(), sizeof(float) * bn.size(), hipMemcpyHostToDevice));
     }
     s->n_boxes = mesh->bvhbox_count;
     s->n_tris = mesh->poly_count;
@@ -921,6 +937,7 @@ static void rt_build_frame_aux(const rt_scene *s, RtFrameAux *ax)
     ax->box_spheres = s->d_box_spheres;
     ax->tri9 = s->d_tri9;
     ax->tri_bs = s->d_tri_bs;
+    ax->tri_nrm = s->d_tri_nrm;
 }
 
 // Bring the device copy of RtFrameAux up to date (a camera move never changes it).

@@ -787,13 +787,21 @@ __device__ __forceinline__ int build_list2(const float4 *tab, const RtFrameConst
     return count;
 }
 
-// One triangle of a leaf against the beam, by its bounding sphere ts = {centre, radius} (host side:
-// rt_scene_set_mesh; radius = +inf for ill-shaped triangles, which are never culled). Keep it unless
-// every ray of the beam passes the sphere at more than pad = 2e-3 + 1e-3 (dist + r): Moller-Trumbore
-// (kernel.cu:1024-1059) can only accept a ray whose line comes closer to the triangle than its own
-// rounding error, which for a triangle whose smallest corner sine is >= 0.1 is below 4 eps |s| / sin^2
-// = 2.4e-5 |s| (|s| <= dist + r: the distance from the ray origin to the first vertex) -- 40 times less.
-__device__ __forceinline__ bool beam_keeps_triangle(const Beam &b, float4 ts)
+// One triangle of a leaf against the beam, by its bounding sphere ts = {centre, radius} and tn = {unit normal, kappa}
+// (host side: rt_scene_set_mesh). Moller-Trumbore (kernel.cu:1024-1059) accepts a ray when its computed barycentrics
+// lie in the unit simplex. Their rounding errors are those of two 3x3 determinants (absolute error <= gamma |s| |e|,
+// gamma ~ 10 eps, |s| the distance from the ray origin to the first vertex) divided by a = D . (e2 x e1) =
+// |e1| |e2| sin(phi0) cos(theta_n), theta_n the angle between the ray and the normal: in the triangle's plane they
+// displace the hit point by at most 2 gamma (|s| + |e|) / (sigma |cos(theta_n)|), sigma the smallest corner sine. For a
+// ray with |cos(theta_n)| >= kappa = 3e-3 / sigma that is below 4e-4 (|s| + |e|), inside pad = 2e-3 + 1e-3 (dist + r)
+// (|s| <= dist + r, |e| <= 2 r): such a ray can only be accepted if its line comes within pad of the triangle, hence
+// of its bounding sphere. A ray that GRAZES the triangle's plane is another matter: the error grows like
+// 1 / cos(theta_n) (float Moller-Trumbore does accept rays that pass the sphere at several radii once cos(theta_n)
+// drops below 3e-4: tools/mt_grazing.py), so a triangle is only culled when every ray of the beam keeps
+// |cos(theta_n)| >= kappa, i.e. |n . u| >= (kappa + k)(1 + k) for the beam's axis u and slope k. A well-shaped
+// triangle is "edge-on" to 0.5 % of the directions, a sliver (sigma -> 0, kappa >= 1; also anything degenerate or
+// non-finite: normal 0) to all of them: never culled.
+__device__ __forceinline__ bool beam_keeps_triangle(const Beam &b, float4 ts, float4 tn)
 {
     const float vx = ts.x - b.ax, vy = ts.y - b.ay, vz = ts.z - b.az;
     const float vv = __builtin_fmaf(vx, vx, __builtin_fmaf(vy, vy, vz * vz));
@@ -803,7 +811,9 @@ __device__ __forceinline__ bool beam_keeps_triangle(const Beam &b, float4 ts)
     const float rc = __builtin_fmaf(1.0e-3f, dist + ts.w, ts.w + 2.0e-3f) * 1.0001f;
     const float reach = sa + rc - b.smin;
     const float rad = __builtin_fmaf(b.k, __builtin_fmaxf(reach, 0.f), b.r0) + rc;
-    return !(reach < 0.f) && !(d2 > rad * rad * 1.0005f);   // NaN / inf keep the triangle
+    const float nu = __builtin_fabsf(__builtin_fmaf(tn.x, b.ux, __builtin_fmaf(tn.y, b.uy, tn.z * b.uz)));
+    const bool facing = nu >= (tn.w + b.k) * (1.f + b.k);              // false for a NaN anywhere
+    return !facing | (!(reach < 0.f) & !(d2 > rad * rad * 1.0005f));   // NaN / inf keep the triangle
 }
 
 // Leaf boxes of the mesh that the beam can touch, as indices in leaf order. A ray
@@ -1124,6 +1134,8 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
 
     unsigned long long hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_walks = 0, st_walks_no_penumbra = 0, st_pen_lanes = 0, st_walk_lanes = 0;
+    unsigned long long st_walks_all_dark = 0, st_walks_all_lit = 0;
+    unsigned long long sm_plisted = 0, sm_pleaf = 0, sm_ptri = 0, sm_slisted = 0, sm_sslab = 0, sm_stri = 0;   // mesh work (STATS, MESH)
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = 0;
     const bool span_only = RT_ABL(512);   // no inner stamps: near-real wave durations
@@ -1214,6 +1226,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
                     }
                     pbeam = b;
                     pbeam_ok = !force_slow;
+                    if (STATS == 1) sm_plisted += (unsigned long long)pbcount;
                 }
             }
         }
@@ -1232,32 +1245,41 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
                 const RtBoxDev bx = ax->boxes[j];
                 const bool bh = box_intersect(bx, O, inv);
                 if (__any(bh) && !RT_ABL(1024)) {
+                    if (STATS == 1) sm_pleaf += 1;
                     // which of the leaf's triangles the tile's beam can touch at all (a leaf of the reference's
-                    // ten-pass split holds triangles far larger than a tile: about a third survive)
-                    unsigned long long tmask = ~0ull;
-                    if (CULL && pbeam_ok && bx.len <= 64) {
-                        const float4 ts = reinterpret_cast<const float4 *>(ax->tri_bs)[bx.start + (lane < bx.len ? lane : 0)];
-                        tmask = __ballot(lane < bx.len && beam_keeps_triangle(pbeam, ts));
-                    }
-                    // the leaf's vertices, seven triangles (63 floats) per coalesced load, staged in LDS
-                    // and broadcast from there: one memory round trip per seven triangles instead of
-                    // two dependent scalar loads per triangle
-                    for (int base = 0; base < bx.len; base += 7) {
-                        const int cnt = bx.len - base < 7 ? bx.len - base : 7;
-                        if (((tmask >> base) & 0x7full) == 0) continue;
-                        mytri[lane] = ax->tri9[(size_t)(bx.start + base) * 9 + lane];   // the array is padded by 64 floats
-                        wave_lds_sync();
-                        for (int i = 0; i < cnt; ++i) {
-                            if (!((tmask >> (base + i)) & 1ull)) continue;
-                            const float *tv = mytri + 9 * i;
-                            float t, u, v;
-                            if (bh && tri_intersect(O, D, tv, tv + 3, tv + 6, t, u, v) && t < nt) {
-                                nt = t;
-                                htri = bx.start + base + i;   // position in tri_idx; resolved when shading (u, v too)
-                                hkind = 0;
-                            }
+                    // ten-pass split holds triangles far larger than a tile: about a third survive), 63 triangles
+                    // -- nine loads of seven -- at a time: the split leaves a few leaves of a hundred and more
+                    for (int c0 = 0; c0 < bx.len; c0 += 63) {
+                        const int clen = bx.len - c0 < 63 ? bx.len - c0 : 63;
+                        unsigned long long tmask = ~0ull;
+                        if (CULL && pbeam_ok) {
+                            const int ti = bx.start + c0 + (lane < clen ? lane : 0);
+                            const float4 ts = reinterpret_cast<const float4 *>(ax->tri_bs)[ti];
+                            const float4 tn = reinterpret_cast<const float4 *>(ax->tri_nrm)[ti];
+                            tmask = __ballot(lane < clen && beam_keeps_triangle(pbeam, ts, tn));
+                            if (tmask == 0) continue;
                         }
-                        wave_lds_sync();
+                        // the leaf's vertices, seven triangles (63 floats) per coalesced load, staged in LDS
+                        // and broadcast from there: one memory round trip per seven triangles instead of
+                        // two dependent scalar loads per triangle
+                        for (int base = 0; base < clen; base += 7) {
+                            const int cnt = clen - base < 7 ? clen - base : 7;
+                            if (((tmask >> base) & 0x7full) == 0) continue;
+                            mytri[lane] = ax->tri9[(size_t)(bx.start + c0 + base) * 9 + lane];   // the array is padded by 64 floats
+                            wave_lds_sync();
+                            for (int i = 0; i < cnt; ++i) {
+                                if (!((tmask >> (base + i)) & 1ull)) continue;
+                                const float *tv = mytri + 9 * i;
+                                float t, u, v;
+                                if (STATS == 1) sm_ptri += 1;
+                                if (bh && tri_intersect(O, D, tv, tv + 3, tv + 6, t, u, v) && t < nt) {
+                                    nt = t;
+                                    htri = bx.start + c0 + base + i;   // position in tri_idx; resolved when shading (u, v too)
+                                    hkind = 0;
+                                }
+                            }
+                            wave_lds_sync();
+                        }
                     }
                 }
             }
@@ -1610,7 +1632,10 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
                             wave_lds_sync();
                             continue;
                         }
-                        if (MESH) {
+                        if (MESH && RT_ABL(32768)) {
+                            sb_use_list = true;
+                            sbcount = 0;
+                        } else if (MESH) {
                             const int cbx = build_box_list(reinterpret_cast<const float4 *>(ax->box_spheres), fc.n_boxes, myboxes, myboxes + RT_BOX_CAP, b, lane);
                             if (cbx <= RT_BOX_CAP) {
                                 sb_use_list = true;
@@ -1718,13 +1743,14 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
                     }
                     // triangles, kernel.cu:1475-1497 (the reference tests them first; an
                     // any-hit does not depend on the order)
-                    if (MESH && !__all(shadowed)) {
+                    if (MESH && !__all(shadowed) && !RT_ABL(8192)) {
                         const V3 inv{1.f / new_dir.x, 1.f / new_dir.y, 1.f / new_dir.z};
                         for (int bjj = 0; bjj < sbcount; ++bjj) {
                             const int bj = sb_use_list ? myboxes[bjj] : bjj;
                             const RtBoxDev bx = ax->boxes[bj];
                             const bool bh = !shadowed && box_intersect(bx, start, inv);
-                            if (__any(bh)) {
+                            if (STATS == 1) sm_sslab += 1;
+                            if (__any(bh) && !RT_ABL(16384)) {
                                 // (a per-triangle cull against the light's beam, as for the primary rays, was measured:
                                 // -1.7 % at 4K, +2.8 % at 1080p, one more spilled register -- not kept)
                                 for (int base = 0; base < bx.len; base += 7) {
@@ -1734,6 +1760,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
                                     for (int i = 0; i < cnt; ++i) {
                                         const float *tv = mytri + 9 * i;
                                         float t, u, v;
+                                        if (STATS == 1) sm_stri += 1;
                                         if (bh && !shadowed && tri_intersect(start, new_dir, tv, tv + 3, tv + 6, t, u, v))
                                             shadowed = true;
                                     }
@@ -1763,10 +1790,13 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
                     phase(7);
                 }
                 if (CULL) wave_lds_sync();
+                if (STATS == 1 && MESH && !all_clear) sm_slisted += (unsigned long long)sbcount;
                 if (STATS == 1 && !all_clear) {   // how many of the walked lights had a lane in a penumbra at all
                     const bool pen = lit && unshadowed != 0 && unshadowed != RT_SHADOW_SAMPLES;
                     st_walks += 1;
                     st_walks_no_penumbra += __any(pen) ? 0 : 1;
+                    st_walks_all_dark += __any(lit && unshadowed != 0) ? 0 : 1;
+                    st_walks_all_lit += __any(lit && unshadowed != RT_SHADOW_SAMPLES) ? 0 : 1;
                     st_pen_lanes += (unsigned long long)__popcll(__ballot(pen));
                     st_walk_lanes += (unsigned long long)__popcll(__ballot(lit));
                 }
@@ -1865,9 +1895,20 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
             atomicAdd(&fc.stats[7], st_overflow);
             for (int k = 0; k < 8; ++k) atomicAdd(&fc.stats[8 + k], hist[k]);
             atomicAdd(&fc.stats[17], st_walks);               // (slots 17.. hold the wave-duration histogram in MODE 3)
-            atomicAdd(&fc.stats[18], st_walks_no_penumbra);
-            atomicAdd(&fc.stats[19], st_pen_lanes);
-            atomicAdd(&fc.stats[20], st_walk_lanes);
+            if (MESH) {   // mesh launches: the mesh's work instead of the penumbra counters (tools/mesh_stats.py)
+                atomicAdd(&fc.stats[18], sm_plisted);
+                atomicAdd(&fc.stats[19], sm_pleaf);
+                atomicAdd(&fc.stats[20], sm_ptri);
+                atomicAdd(&fc.stats[21], sm_slisted);
+                atomicAdd(&fc.stats[22], sm_sslab);
+                atomicAdd(&fc.stats[23], sm_stri);
+            } else {
+                atomicAdd(&fc.stats[18], st_walks_no_penumbra);
+                atomicAdd(&fc.stats[19], st_pen_lanes);
+                atomicAdd(&fc.stats[20], st_walk_lanes);
+                atomicAdd(&fc.stats[21], st_walks_all_dark);
+                atomicAdd(&fc.stats[22], st_walks_all_lit);
+            }
             atomicAdd(&fc.stats[16], st_clusters);
         }
     }

@@ -232,3 +232,60 @@ def test_mesh_fuzz_triangle_soup(rt, gpu, seed):
     inp = sc
     inp.scene_obj = None
     _render_both(rt, inp, txt, 96, 64)
+
+
+def _grazing_triangles_obj(rt, cam_org, w, h, aspect, rows, per_row, seed):
+    """Triangles lying (almost) in the planes that whole pixel ROWS of rays span: with yaw = pitch = 0 the rays of row
+    y are O + s (dx, dy(y), 1/aspect), O = cam.Org + (0, 0, -1/aspect) (kernel.cu:1624-1631), a plane through O. Tilted
+    out of that plane by 0 ... 1e-3 rad they are grazed by hundreds of rays -- where Moller-Trumbore's rounding error
+    is unbounded and a bounding-sphere cull alone would be unsound (beam_keeps_triangle's edge-on guard)."""
+    rng = np.random.default_rng(seed)
+    ez = 1.0 / aspect
+    O = np.array([cam_org[0], cam_org[1], cam_org[2] - ez])
+    lines = []
+    for y in rows:
+        dy = float(np.float32(aspect * (2 * (y + 0.5) / np.float32(h)) * (np.float32(h) / w) - 1))
+        for _ in range(per_row):
+            tilt = float(rng.choice([0.0, 1e-6, -1e-5, 1e-4, -3e-4, 1e-3])) + float(rng.normal()) * 1e-6
+            f0 = np.array([0.0, dy, ez]); f0 /= np.linalg.norm(f0)                    # forward, in the row plane
+            n = np.array([0.0, f0[2], -f0[1]])                                        # the row plane's normal
+            f = f0 * np.cos(tilt) + n * np.sin(tilt)                                  # the triangle's plane: tilted about the
+            dist, x0, size = rng.uniform(2.5, 9.0), rng.uniform(-3.0, 3.0), float(rng.choice([0.15, 0.5, 1.5]))
+            c = O + f0 * dist + np.array([x0, 0.0, 0.0])                              # line {c + a e_x}, which the row's rays meet
+            for _ in range(3):
+                a, b = rng.normal(size=2) * size
+                p = c + np.array([a, 0.0, 0.0]) + f * b
+                lines.append("v %.7f %.7f %.7f" % tuple(p))
+    nt = len(lines) // 3
+    lines += ["f %d %d %d" % (3 * i + 1, 3 * i + 2, 3 * i + 3) for i in range(nt)]
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.gpu
+def test_mesh_triangles_grazed_by_whole_pixel_rows(rt, gpu):
+    """Culled == brute force == oracle where rays run (almost) inside triangle planes."""
+    from test_gpu_scenarios import Scn, _cam
+    w, h = 224, 144
+    org = (0.5, 0.25, -1.0)
+    sc = Scn(rt, [(0.5, 0.0, 7.0, 0.8), (2.5, 1.0, 6.0, 0.6)], cam=_cam(rt, org, 0.0, 0.0))
+    txt = _grazing_triangles_obj(rt, org, w, h, sc.aspect, rows=range(8, h - 8, 9), per_row=4, seed=11)
+    cnt = _render_both(rt, sc, txt, w, h)
+    assert cnt["hit_pixels"] > 500
+
+
+@pytest.mark.gpu
+def test_mesh_grazing_rows_full_hd_cull_equals_brute(rt, gpu):
+    """The same at 1920x1080 (thin beams, 300 000 grazing ray/triangle pairs): culling kernel against the brute-force one."""
+    import torch
+    from test_gpu_scenarios import Scn, _cam
+    w, h = 1920, 1080
+    org = (0.5, 0.25, -1.0)
+    sc = Scn(rt, [(0.5, 0.0, 7.0, 0.8)], cam=_cam(rt, org, 0.0, 0.0))
+    txt = _grazing_triangles_obj(rt, org, w, h, sc.aspect, rows=range(20, h - 20, 13), per_row=3, seed=12)
+    scene = sc.scene()
+    scene.set_mesh(rt.mesh_from_obj_text(txt))
+    a = scene.render(w, h, cam=sc.cam, cull=True)
+    b = scene.render(w, h, cam=sc.cam, cull=False)
+    torch.cuda.synchronize()
+    assert torch.equal(a["rgba"].view(torch.int32), b["rgba"].view(torch.int32))
+    assert torch.equal(a["packed"], b["packed"])
