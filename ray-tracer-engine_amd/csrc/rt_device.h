@@ -22,13 +22,12 @@
                                // that add 0.6 GB of scratch writes per frame.
 #endif
 #ifndef RT_MIN_WAVES_ONE_SAMPLE
-#define RT_MIN_WAVES_ONE_SAMPLE 6 // the one-sample kernels without a mesh (every BASELINE config at 1 spp, and each pass of the
-                               // hipGraph frame) fit 80 registers without a spill: 6 waves per SIMD
+#define RT_MIN_WAVES_ONE_SAMPLE 7 // the one-sample kernels without a mesh (every BASELINE config at 1 spp, and each pass of the
+                               // hipGraph frame) fit 72 registers without a spill (compiled without the SLP vectoriser, see
+                               // the Makefile): 7 waves per SIMD. (Their work-counter builds get RT_MIN_WAVES_PER_SIMD.)
 #endif
 #ifndef RT_MIN_WAVES_MESH
-#define RT_MIN_WAVES_MESH 5      // one-sample kernels with the triangle-mesh branches: 96 registers. The compiler then spills
-                                 // 2 of them (12 B of scratch per lane); measured against the 4-wave budget, which spills
-                                 // nothing: 2.14 vs 2.25 ms on the 4K / 7 520-triangle frame, so 5 it is
+#define RT_MIN_WAVES_MESH 5      // one-sample kernels with the triangle-mesh branches: 89 of 96 registers, no spill
 #endif
 #ifndef RT_MIN_WAVES_MESH_MULTI
 #define RT_MIN_WAVES_MESH_MULTI 4 // ... with a sample loop or work counters on top: 128 registers, no spill

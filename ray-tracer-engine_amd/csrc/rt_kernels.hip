@@ -1045,7 +1045,7 @@ __device__ __forceinline__ void shadow_test(const RayK &sr, float4 s, bool &shad
 // MULTI: the launch may take several samples per pixel (rt_launch_opts.spp > 1). The
 // one-sample kernel has no sample loop: 74 -> 22 spilled scalars and 15 fewer vector registers.
 template <int TW, bool CULL, int MODE, bool TABLDS, int FEAT = 0, bool MULTI = true>
-__global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? (MODE == 1 ? 3 : (MULTI || TABLDS) ? RT_MIN_WAVES_MESH_MULTI : RT_MIN_WAVES_MESH) : (!MULTI && !TABLDS) ? RT_MIN_WAVES_ONE_SAMPLE : RT_MIN_WAVES_PER_SIMD) void rt_trace_tiles(const RtFrameConsts fc,
+__global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? (MODE == 1 ? 3 : (MULTI || TABLDS) ? RT_MIN_WAVES_MESH_MULTI : RT_MIN_WAVES_MESH) : (MODE == 1) ? 4 : (!MULTI && !TABLDS) ? RT_MIN_WAVES_ONE_SAMPLE : RT_MIN_WAVES_PER_SIMD) void rt_trace_tiles(const RtFrameConsts fc,
                                                                      const float4 *__restrict__ spheres)
 {
     constexpr int STATS = (MODE == 1) ? 1 : (MODE == 3) ? 2 : 0;
