@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Copy the summaries of a tools/final_pass.sh run (gpurun_out/<tag>/) into profiles/<name>_*: what DESIGN.md quotes."""
+import json, os, shutil, subprocess, sys
+tag, name = sys.argv[1], sys.argv[2]
+src = os.path.join("gpurun_out", tag)
+line = [l for l in open(os.path.join(src, "bench.json")).read().strip().splitlines() if l.startswith("{")][-1]
+json.dump(json.loads(line), open(f"profiles/{name}_bench_c3_n1.json", "w"), indent=1)
+subprocess.check_call([sys.executable, "tools/summarize_profile.py", tag, f"{name}_c3_frame_kernel"], stdout=subprocess.DEVNULL)
+subprocess.check_call([sys.executable, "tools/summarize_profile.py", tag + "_tablds", f"{name}_c3_table_lds"], stdout=subprocess.DEVNULL)
+for f in ("other_configs", "mesh_scenes", "fast_mode", "host_overhead_single_stream", "host_overhead_two_streams",
+          "multi_one_gpu_rehearsal"):
+    s = open(os.path.join(src, f + ".json")).read()
+    open(f"profiles/{name}_{f}.json", "w").write(s[s.index("{"):])   # (RCCL prints a banner to stdout)
+shutil.copy(os.path.join(src, "ablation_pmc.txt"), f"profiles/{name}_ablation_pmc.txt")
+abl = json.load(open(os.path.join(src, "mesh_ablate.json")))
+json.dump({"scene": "3840x2160, 1024 spheres + uv-sphere mesh of 7520 triangles / 756 leaves (tools/bench_mesh.py)",
+           "ms_with_parts_skipped_tuning_build": {k: v["ms"] for k, v in abl.items()},
+           "work_counters": json.load(open(os.path.join(src, "mesh_stats.json")))},
+          open(f"profiles/{name}_mesh_ablation.json", "w"), indent=1)
+print("profiles/%s_* written" % name)
