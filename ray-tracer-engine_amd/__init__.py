@@ -195,6 +195,7 @@ def load_library():
         "rt_scene_set_texture": (ci, [vp, fp, fp, fp, ci, ci]),
         "rt_scene_set_sky": (ci, [vp, C.POINTER(Sphere), fp, fp, fp, ci, ci]),
         "rt_scene_set_lights": (ci, [vp, C.POINTER(Light), ci]),
+        "rt_scene_set_tile_order": (ci, [vp, ci]),
         "rt_scene_render": (ci, [vp, C.POINTER(FrameDesc), vp]),
         "rt_graph_capture": (vp, [vp, C.POINTER(FrameDesc), ci, vp, vp]),
         "rt_graph_launch": (ci, [vp, vp]),
@@ -371,6 +372,10 @@ class Scene:
     def set_lights(self, lights, n):
         _check(self.lib.rt_scene_set_lights(self.handle, lights, n), "rt_scene_set_lights")
         self.lights, self.n_lights = lights, n
+
+    def set_tile_order(self, mode: int):
+        """1 (default): launches start their longest tiles first (durations of earlier frames); 0: grid order."""
+        _check(self.lib.rt_scene_set_tile_order(self.handle, mode), "rt_scene_set_tile_order")
 
     @classmethod
     def default(cls, n_spheres: int = 1024, seed: int = 1) -> "Scene":

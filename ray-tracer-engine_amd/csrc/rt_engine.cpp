@@ -135,6 +135,21 @@ struct ConeSlot {
     bool build_pending = false;           // `built` not yet seen complete: readers wait on it (on the device)
 };
 
+#define RT_ORDER_SLOTS 4
+#define RT_ORDER_EVERY 32            // an unchanged view: the order is sorted again from fresh durations every so many launches
+#define RT_ORDER_STATIC_LAUNCHES 4   // ... and for the first time once the view has been the same for this many
+struct TileOrder {
+    int key[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // tile width, frame width / height, y0, y1, local rows, interleave
+                                                  // count / index / rows, and which kernel: cull, mode, samples
+    unsigned *cost = nullptr, *perm = nullptr;  // one allocation: [cap] durations, [cap] order
+    size_t cap = 0;
+    int n = 0, tiles_x = 0;
+    float view[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // camera and sphere list the last launch saw
+    int same_view = 0;                           // consecutive launches of that view so far
+    bool have_perm = false;
+    unsigned long long last_use = 0;
+};
+
 struct rt_scene {
     float4 *d_spheres = nullptr;     // [n] list order | [n_pad] Morton order | [n_blocks] block bounds | [n_pad] ints
     int n_spheres = 0, cap_spheres = 0;
@@ -192,6 +207,14 @@ struct rt_scene {
     unsigned long long ring_seq = 0;     // sequence number of the next launch
     // bumped whenever a buffer a recorded graph may point into is rewritten or re-allocated
     unsigned long long epoch = 0;
+    // order of the tiles within a launch (RtFrameConsts::tile_perm / tile_cost, rt_tables.hip): per launch
+    // layout (which rows of which frame, tile shape) the tiles' wave durations as the frame kernel records
+    // them and, rebuilt from those every RT_ORDER_EVERY launches, the order that starts the longest first
+    TileOrder orders[RT_ORDER_SLOTS];
+    unsigned long long order_clock = 0;      // for least-recently-used replacement
+    int tile_order_mode = 1;                 // rt_scene_set_tile_order
+    hipEvent_t order_built = nullptr;        // the last rebuild; launches on other streams wait for it on the device
+    bool order_pending = false;
 #ifdef RT_TUNING
     int tune_no_eye_cones = 0, tune_no_light_columns = 0, tune_table_lds = 0, tune_ablate = 0;
 #endif
@@ -277,6 +300,9 @@ extern "C" void rt_scene_destroy(rt_scene *s)
     if (s->d_tri_bs) (void)hipFree(s->d_tri_bs);
     if (s->d_tri_nrm) (void)hipFree(s->d_tri_nrm);
     if (s->d_light_tabs) (void)hipFree(s->d_light_tabs);
+    for (TileOrder &o : s->orders)
+        if (o.cost) (void)hipFree(o.cost);
+    if (s->order_built) (void)hipEventDestroy(s->order_built);
     for (ConeSlot &c : s->cones) {
         if (c.buf) (void)hipFree(c.buf);
         if (c.built) (void)hipEventDestroy(c.built);
@@ -1150,6 +1176,85 @@ int rt_scene_prepare_static(rt_scene *s, const rt_frame_desc *fd, hipStream_t st
     return rt_scene_sync_aux(s);
 }
 
+// The frame kernel records every tile's wave duration (two s_memtime and one store per wave: free). While the view
+// -- camera and sphere list -- stays what it was, the tiles are sorted "longest first" from the previous launch's
+// durations (one workgroup on the launching stream, ~80 us: after 4, 8, 16, 32, 64, ... launches of the unchanged
+// view) and the launches start their tiles in that order. A view that changes renders in grid order: the expensive
+// tiles move by several tiles per camera step, and an order one step old is worth nothing (measured: 3 % WORSE than
+// grid order, which at least keeps neighbouring tiles together; tools/tile_order_sim.py). Scheduling only -- every
+// tile is rendered once, by the same instructions. Ordering against frames in flight: the sort waits (on the device)
+// for every frame launched so far, which read the old order; frames launched afterwards on other streams wait for
+// the sort's event.
+static int rt_scene_prepare_tile_order(rt_scene *s, const RtKernelChoice &kc, RtFrameConsts *fc, hipStream_t stream)
+{
+    const int tile_w = kc.tile, th = 64 / tile_w;
+    const int tiles_x = (fc->width + tile_w - 1) / tile_w, tiles_y = (fc->local_rows + th - 1) / th;
+    if (tiles_x > 0xffff || tiles_y > 0xffff) return RT_OK;            // does not fit the packed form: grid order
+    const int n = tiles_x * tiles_y;
+    const int key[12] = {tile_w, fc->width, fc->height, fc->y0, fc->y1, fc->local_rows, fc->il_count, fc->il_index, fc->il_rows,
+                         kc.cull, kc.mode, fc->spp};
+    // what the durations depend on from frame to frame: the view and the sphere list
+    const float view[8] = {fc->org_x, fc->org_y, fc->org_z, fc->cos_pitch, fc->sin_pitch, fc->cos_yaw, fc->sin_yaw,
+                           (float)(s->sphere_gen & 0xffffff)};
+    TileOrder *t = nullptr, *lru = &s->orders[0];
+    for (TileOrder &o : s->orders) {
+        if (o.cap && memcmp(o.key, key, sizeof key) == 0) t = &o;
+        if (o.last_use < lru->last_use) lru = &o;
+    }
+    if (s->order_pending) {   // an order being sorted (any layout: one event) precedes this launch
+        if (hipEventQuery(s->order_built) == hipSuccess) s->order_pending = false;
+        else RT_HIP(hipStreamWaitEvent(stream, s->order_built, 0));
+        (void)hipGetLastError();
+    }
+    if (!t) {                 // a new layout takes the least recently used slot
+        t = lru;
+        int rc = stream_wait_all_frames(s, stream);   // frames that still write into the slot's old arrays
+        if (rc != RT_OK) return rc;
+        if ((size_t)n > t->cap) {
+            rc = rt_scene_quiesce(s);                  // re-allocation: nothing may still use the old arrays
+            if (rc != RT_OK) return rc;
+            if (t->cost) RT_HIP(hipFree(t->cost));
+            t->cost = t->perm = nullptr;
+            t->cap = 0;
+            const size_t cap = ((size_t)n + 3) & ~(size_t)3;     // the sort reads four at a time
+            RT_HIP(hipMalloc((void **)&t->cost, sizeof(unsigned) * 2 * cap));
+            t->cap = cap;
+        }
+        t->perm = t->cost + t->cap;
+        RT_HIP(hipMemsetAsync(t->cost, 0, sizeof(unsigned) * t->cap, stream));
+        memcpy(t->key, key, sizeof key);
+        memcpy(t->view, view, sizeof view);
+        t->n = n;
+        t->tiles_x = tiles_x;
+        t->same_view = 0;
+        t->have_perm = false;
+        if (!s->order_built) RT_HIP(hipEventCreateWithFlags(&s->order_built, hipEventDisableTiming));
+        RT_HIP(hipEventRecord(s->order_built, stream));   // launches on other streams: after the reset
+        s->order_pending = true;
+    } else if (memcmp(t->view, view, sizeof view) != 0) {
+        memcpy(t->view, view, sizeof view);
+        t->same_view = 0;                              // this launch and the next ones: grid order
+        t->have_perm = false;
+    } else {
+        // launches of this view so far: t->same_view, all of which recorded durations; sort after 4, 8, 16, 32, 64, 96, ...
+        const int k = t->same_view;
+        if (k >= RT_ORDER_STATIC_LAUNCHES && ((k & (k - 1)) == 0 || k % RT_ORDER_EVERY == 0)) {
+            int rc = stream_wait_all_frames(s, stream);
+            if (rc != RT_OK) return rc;
+            RT_HIP(rt_tile_order_launch(t->cost, t->perm, t->n, t->tiles_x, stream));
+            if (!s->order_built) RT_HIP(hipEventCreateWithFlags(&s->order_built, hipEventDisableTiming));
+            RT_HIP(hipEventRecord(s->order_built, stream));
+            s->order_pending = true;
+            t->have_perm = true;
+        }
+    }
+    t->same_view++;
+    t->last_use = ++s->order_clock;
+    fc->tile_cost = t->cost;
+    fc->tile_perm = t->have_perm ? t->perm : nullptr;
+    return RT_OK;
+}
+
 extern "C" int rt_scene_render(rt_scene *s, const rt_frame_desc *fd, void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
@@ -1192,8 +1297,22 @@ extern "C" int rt_scene_render(rt_scene *s, const rt_frame_desc *fd, void *strea
     rc = rt_frame_kernel_choice(s, fd, &kc);
     if (rc != RT_OK) return rc;
     if (fc.local_rows == 0) return RT_OK;   // this rank owns no rows of the frame
+    if (s->tile_order_mode != 0 && !kc.table_lds) {
+        rc = rt_scene_prepare_tile_order(s, kc, &fc, stream);
+        if (rc != RT_OK) return rc;
+    }
     RT_HIP(rt_dev_launch_trace(&fc, s->d_spheres, kc.tile, kc.cull, kc.mode, kc.table_lds, kc.feat, stream));
     return rt_scene_note_launch(s, stream, slot);
+}
+
+extern "C" int rt_scene_set_tile_order(rt_scene *s, int mode)
+{
+    if (!s || (mode != 0 && mode != 1)) {
+        rt_set_error("rt_scene_set_tile_order: null scene or mode %d not in {0, 1}", mode);
+        return RT_ERR_INVALID;
+    }
+    s->tile_order_mode = mode;
+    return RT_OK;
 }
 
 // For rt_graph.cpp: the scene's buffers a graph node needs.

@@ -1117,11 +1117,23 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
     }
     wave_lds_sync();
 
-    const int tile_x = (blockIdx.x * WGX + (wave % WGX)) * TW;
+    // which tile: the workgroup's own, or (one-wave workgroups) the one the frame's tile order puts at this place
+    unsigned blk_x = blockIdx.x, blk_y = blockIdx.y;
+    unsigned long long t_start = 0;
+    const unsigned tiles_x = (unsigned)(fc.width + TW - 1) / (unsigned)TW;   // = gridDim.x of a one-wave-workgroup launch
+    if (!TABLDS) {
+        if (fc.tile_perm) {
+            const unsigned p = fc.tile_perm[blockIdx.y * tiles_x + blockIdx.x];
+            blk_x = p & 0xffffu;
+            blk_y = p >> 16;
+        }
+        if (fc.tile_cost) t_start = __builtin_amdgcn_s_memtime();
+    }
+    const int tile_x = (blk_x * WGX + (wave % WGX)) * TW;
     // local row -> global row: a contiguous band, or row blocks dealt round-robin
     // to the ranks of a multi-GPU frame (il_rows is a multiple of the tile rows a
     // workgroup covers, so a tile never straddles two blocks)
-    const int ly = (blockIdx.y * (WPW / WGX) + (wave / WGX)) * TH + (lane / TW);
+    const int ly = (blk_y * (WPW / WGX) + (wave / WGX)) * TH + (lane / TW);
     const int px = tile_x + (lane % TW);
     const int py = (fc.il_count > 1) ? ((ly / fc.il_rows) * fc.il_count + fc.il_index) * fc.il_rows + (ly % fc.il_rows)
                                      : fc.y0 + ly;
@@ -1862,6 +1874,11 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
         // bytes B,G,R of pixel k at 3k..3k+2: dword i of the quad's three
         const unsigned w24 = (p >> (8 * i)) | (pn << (24 - 8 * i));
         if (valid && i < 3) fc.packed24[(size_t)(out_idx >> 2) * 3 + (size_t)i] = w24;
+    }
+
+    if (!TABLDS && fc.tile_cost) {   // this tile's wave duration, for the order of a later frame
+        const unsigned dt = (unsigned)(__builtin_amdgcn_s_memtime() - t_start);
+        if (lane == 0) fc.tile_cost[blk_y * tiles_x + blk_x] = dt;
     }
 
     phase(3, true);

@@ -20,3 +20,8 @@ hipError_t rt_eye_cones_launch(const float4 *tab, int n, const float org[3], flo
 // The same launch as a graph kernel node: function, geometry and dynamic LDS; the arguments are
 // (const float4 *tab, int n, float ox, float oy, float oz, float4 *out).
 void rt_eye_cones_kernel_config(int n, int threads, const void **func, dim3 *grid, dim3 *block, unsigned *lds_bytes);
+
+// Order of the tiles of a launch, longest first (RtFrameConsts::tile_perm): a counting sort of `n` tiles by the wave
+// durations of an earlier frame (cost[], shader clocks; 0 = never rendered) into perm[] = (tile_y << 16) | tile_x,
+// one workgroup on `stream`. Always a permutation of the n tiles, whatever cost[] holds.
+hipError_t rt_tile_order_launch(const unsigned *cost, unsigned *perm, int n, int tiles_x, hipStream_t stream);

@@ -815,3 +815,31 @@ def test_fast_mode_stays_within_the_tolerance_away_from_flips(rt, gpu):
     for kw in (dict(cull=False), dict(tile=16), dict(want_stats=True), dict(force_slow=True), dict(table_lds=True)):
         g, pg, _ = _render(scene, w, h, fast=True, **kw)
         assert np.array_equal(_bits(g), _bits(e)) and np.array_equal(pg, pe), kw
+
+
+@pytest.mark.gpu
+def test_tile_order_changes_the_schedule_not_the_pixels(rt, gpu):
+    """rt_scene_set_tile_order: longest-first launches (sorted from wave durations the kernel records, after 4, 8,
+    16, ... launches of an unchanged view) render the same bits as grid-order launches -- whole frame, a row band,
+    interleaved rows, two streams sharing the scene, a camera that rests and moves, layouts evicting each other."""
+    import torch
+    w, h = 640, 360
+    scene = rt.Scene.default(256)
+    plain = rt.Scene.default(256)
+    plain.set_tile_order(0)
+    cams = []
+    for k in range(80):
+        cam = rt.default_camera()
+        cam.Org.z += 0.05 * ((k // 12) % 7)        # rests for twelve launches (six per layout), then moves
+        cam.Camyaw += 0.5 * ((k // 12) % 5) + (0.25 * (k % 3) if 36 <= k < 48 else 0.0)   # ... and once keeps moving
+        cams.append(cam)
+    layouts = [dict(), dict(y0=64, y1=200), dict(interleave=(3, 1, 16)), dict(tile=16), dict(y0=0, y1=72), dict(interleave=(2, 0, 16))]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for k, cam in enumerate(cams):
+        kw = layouts[(k // 3) % len(layouts)] if k >= 70 else layouts[k % 2]     # two layouts alternating (35 launches each), then all six
+        with torch.cuda.stream(streams[k & 1]):
+            a = scene.render(w, h, cam=cam, stream=streams[k & 1], **kw)
+        b = plain.render(w, h, cam=cam, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(a["packed"], b["packed"]), (k, kw)
+        assert torch.equal(a["rgba"].view(torch.int32), b["rgba"].view(torch.int32)), (k, kw)
