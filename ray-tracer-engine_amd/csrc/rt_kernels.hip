@@ -1119,7 +1119,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
 
     // which tile: the workgroup's own, or (one-wave workgroups) the one the frame's tile order puts at this place
     unsigned blk_x = blockIdx.x, blk_y = blockIdx.y;
-    unsigned long long t_start = 0;
+    unsigned t_start = 0;
     const unsigned tiles_x = (unsigned)(fc.width + TW - 1) / (unsigned)TW;   // = gridDim.x of a one-wave-workgroup launch
     if (!TABLDS) {
         if (fc.tile_perm) {
@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
             blk_x = p & 0xffffu;
             blk_y = p >> 16;
         }
-        if (fc.tile_cost) t_start = __builtin_amdgcn_s_memtime();
+        if (fc.tile_cost) t_start = (unsigned)__builtin_amdgcn_s_memtime();
     }
     const int tile_x = (blk_x * WGX + (wave % WGX)) * TW;
     // local row -> global row: a contiguous band, or row blocks dealt round-robin
@@ -1877,7 +1877,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
     }
 
     if (!TABLDS && fc.tile_cost) {   // this tile's wave duration, for the order of a later frame
-        const unsigned dt = (unsigned)(__builtin_amdgcn_s_memtime() - t_start);
+        const unsigned dt = (unsigned)__builtin_amdgcn_s_memtime() - t_start;
         if (lane == 0) fc.tile_cost[blk_y * tiles_x + blk_x] = dt;
     }
 
