@@ -47,8 +47,10 @@ namespace {
 // kernel's own stores may alias it and uses per-lane vector loads into VGPRs.
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef const RtFrameAux __attribute__((address_space(4))) *AuxPtr;
+typedef const RtFrameConsts __attribute__((address_space(4))) *FcPtr;
 #else
 typedef const RtFrameAux *AuxPtr;   // host pass over this translation unit (device functions are only parsed there)
+typedef const RtFrameConsts *FcPtr;
 #endif
 
 struct V3 {
@@ -1834,12 +1836,22 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
     }
 
     // ================= write-back =================
+    // The frame uniforms of this part -- output pointers, flags, the divisor -- are read from the kernel-argument
+    // segment HERE: taken from `fc` they are loaded at the kernel's entry and held in scalar registers across the whole
+    // kernel, whose scalar file is full (each one more is a v_writelane / v_readlane pair in the loops above).
+    FcPtr kargs = (FcPtr)__builtin_amdgcn_kernarg_segment_ptr();   // `fc` is the first kernel argument
+    asm volatile("" : "+s"(kargs));                                // opaque: not merged with the loads at the entry
+    float *const o_rgba = kargs->rgba;
+    uint32_t *const o_packed = kargs->packed, *const o_packed24 = kargs->packed24;
+    unsigned *const o_cost = kargs->tile_cost;
+    const int o_flags = kargs->flags;
+    const float o_total = kargs->sample_total;
     if (valid) {
         const size_t o = out_idx;
         float w = (float)n_samples;
-        if (fc.rgba) {
-            float4 *dst = reinterpret_cast<float4 *>(fc.rgba) + o;
-            if (fc.flags & RT_FLAG_ACCUMULATE) {
+        if (o_rgba) {
+            float4 *dst = reinterpret_cast<float4 *>(o_rgba) + o;
+            if (o_flags & RT_FLAG_ACCUMULATE) {
                 const float4 old = *dst;
                 acc_r = old.x + acc_r;
                 acc_g = old.y + acc_g;
@@ -1848,24 +1860,24 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
             }
             *dst = make_float4(acc_r, acc_g, acc_b, w);
         }
-        if (fc.packed && (fc.flags & RT_FLAG_RESOLVE)) {
+        if (o_packed && (o_flags & RT_FLAG_RESOLVE)) {
             // mean over the frame's samples (x/1.0f is exact, so 1 spp is the
             // reference's rgbToInt(fr*254, fg*254, fb*254), kernel.cu:1682/1688)
             float mr = acc_r, mg = acc_g, mb = acc_b;
-            if (fc.sample_total != 1.f) {   // wave-uniform; three IEEE divisions saved at 1 spp
-                mr = acc_r / fc.sample_total;
-                mg = acc_g / fc.sample_total;
-                mb = acc_b / fc.sample_total;
+            if (o_total != 1.f) {   // wave-uniform; three IEEE divisions saved at 1 spp
+                mr = acc_r / o_total;
+                mg = acc_g / o_total;
+                mb = acc_b / o_total;
             }
-            fc.packed[o] = rgb_to_int(f2i(mr * 254.f), f2i(mg * 254.f), f2i(mb * 254.f));
+            o_packed[o] = rgb_to_int(f2i(mr * 254.f), f2i(mg * 254.f), f2i(mb * 254.f));
         }
     }
-    if (fc.packed24 && (fc.flags & RT_FLAG_RESOLVE)) {   // wave-uniform; all lanes take part in the quad exchange
+    if (o_packed24 && (o_flags & RT_FLAG_RESOLVE)) {   // wave-uniform; all lanes take part in the quad exchange
         float mr = acc_r, mg = acc_g, mb = acc_b;
-        if (fc.sample_total != 1.f) {
-            mr = acc_r / fc.sample_total;
-            mg = acc_g / fc.sample_total;
-            mb = acc_b / fc.sample_total;
+        if (o_total != 1.f) {
+            mr = acc_r / o_total;
+            mg = acc_g / o_total;
+            mb = acc_b / o_total;
         }
         const unsigned p = rgb_to_int(f2i(mr * 254.f), f2i(mg * 254.f), f2i(mb * 254.f));
         // the next pixel of the quad (lanes 4q..4q+3 hold four consecutive pixels of a row)
@@ -1873,12 +1885,12 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
         const int i = lane & 3;
         // bytes B,G,R of pixel k at 3k..3k+2: dword i of the quad's three
         const unsigned w24 = (p >> (8 * i)) | (pn << (24 - 8 * i));
-        if (valid && i < 3) fc.packed24[(size_t)(out_idx >> 2) * 3 + (size_t)i] = w24;
+        if (valid && i < 3) o_packed24[(size_t)(out_idx >> 2) * 3 + (size_t)i] = w24;
     }
 
-    if (!TABLDS && fc.tile_cost) {   // this tile's wave duration, for the order of a later frame
+    if (!TABLDS && o_cost) {   // this tile's wave duration, for the order of a later frame
         const unsigned dt = (unsigned)__builtin_amdgcn_s_memtime() - t_start;
-        if (lane == 0) fc.tile_cost[blk_y * tiles_x + blk_x] = dt;
+        if (lane == 0) o_cost[blk_y * tiles_x + blk_x] = dt;
     }
 
     phase(3, true);
