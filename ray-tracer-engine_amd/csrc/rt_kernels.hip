@@ -1413,6 +1413,11 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
         V3 start{0.f, 0.f, 0.f}, normal{0.f, 1.f, 0.f};
         float tr = 0.f, tg = 0.f, tb = 0.f;
         if (hit) {
+            // the texture's uniforms: read from the kernel-argument segment here (see the write-back), not carried through
+            // the primary cull and tests
+            FcPtr kt = (FcPtr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kt));
+            const int t_w = kt->tex_w, t_h = kt->tex_h;
             const V3 new_org{O.x + D.x * nt, O.y + D.y * nt, O.z + D.z * nt};
             float tx = 0.5f, ty = 0.5f;   // plane, kernel.cu:1413-1414
             int ci_fast = -1;             // texel index already known for sure (sphere / cube hits of the culling kernels)
@@ -1449,7 +1454,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
                 } else if (LEAN && !RT_ABL(4096)) {
                     float ux, uy;
                     approx_sphere_uv(normal, ux, uy);
-                    ci_fast = sure_texel(ux, uy, fc.tex_w, fc.tex_h, fc.tex_mu_x, fc.tex_mu_y);
+                    ci_fast = sure_texel(ux, uy, t_w, t_h, kt->tex_mu_x, kt->tex_mu_y);
                     if (__builtin_expect(ci_fast < 0, 0)) {
                         tx = (float)((1.0 + rtm::div_by_3p1415((double)rtm::atan2f_rt(normal.z, normal.x, myatan))) * 0.5);
                         ty = (float)rtm::div_by_3p1415((double)rtm::acosf_rt(normal.y, myatan));
@@ -1461,13 +1466,13 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
                     ty = (float)rtm::div_by_3p1415((double)rtm::acosf_rt(normal.y, myatan));
                 }
             }
-            int ci = f2i(ty * (float)fc.tex_h) * fc.tex_w + f2i(tx * (float)fc.tex_w);
+            int ci = f2i(ty * (float)t_h) * t_w + f2i(tx * (float)t_w);
             if (ci_fast >= 0) ci = ci_fast;
-            const int last = fc.tex_w * fc.tex_h - 1;
+            const int last = t_w * t_h - 1;
             ci = ci < 0 ? 0 : (ci > last ? last : ci);       // documented clamp
-            tr = fc.tex_r[ci];
-            tg = fc.tex_g[ci];
-            tb = fc.tex_b[ci];
+            tr = kt->tex_r[ci];
+            tg = kt->tex_g[ci];
+            tb = kt->tex_b[ci];
             // start_O = normal * 0.00001 + new_org, kernel.cu:1647
             start = V3{normal.x * 0.00001f + hp.x, normal.y * 0.00001f + hp.y, normal.z * 0.00001f + hp.z};
             if (STATS == 1) st_hits += 1;
