@@ -320,15 +320,16 @@ def main():
         e_mv, e_st, e_pl, e_go = reduce_max(e_mv, e_st, e_pl, e_go)
         rays = w * h * args.spp
         extras["grid_order"] = {"ms_per_step": e_go / args.steps * 1e3, "Mrays_per_s": rays / (e_go / args.steps) / 1e6,
-                                "note": "rt_scene_set_tile_order(0): tiles started row-major as the grid comes. The default starts the "
-                                        "longest tiles first while the view is unchanged (wave durations recorded by the frame kernel, "
-                                        "sorted on the device after 4, 8, 16, 32, ... launches of the same view) so that a launch does "
-                                        "not drain behind a few expensive tiles; a moving camera renders in grid order"}
+                                "note": "rt_scene_set_tile_order(0): tiles started row-major as the grid comes. The default starts blocks "
+                                        "of 16x16 tiles in the order of their longest tile (wave durations recorded by the frame kernel in "
+                                        "the previous launch, sorted on the device after 1, 2, 4, 8, ... launches of an unchanged view and "
+                                        "every third launch of a moving camera) so that a launch does not drain behind a few expensive tiles"}
         extras["moving_camera"] = {"ms_per_step": e_mv / args.steps * 1e3, "Mrays_per_s": rays / (e_mv / args.steps) / 1e6,
                                    "same_positions_held_ms": e_st / args.steps * 1e3,
                                    "overhead_vs_held": e_mv / e_st - 1.0,
                                    "note": "one frame at a time, cam.Org.z nudged by 0.1 every frame (kernel.cu:1727); eye-cone table "
-                                           "rebuilt by a device kernel on the frame's stream, no host synchronisation"}
+                                           "rebuilt by a device kernel on the frame's stream, tile order re-sorted every third frame, "
+                                           "no host synchronisation"}
         extras["pipelined"] = {"frames_in_flight": 2, "ms_per_step": e_pl / args.steps * 1e3,
                                "Mrays_per_s": rays / (e_pl / args.steps) / 1e6,
                                "note": "consecutive frames alternate between two HIP streams with their own framebuffers"}
@@ -401,7 +402,7 @@ def main():
                                    + ("(whole table staged in LDS per workgroup)" if args.table_lds else
                                       "(the 16 KiB tables themselves are read from L2; opts.table_lds stages them whole)"),
                        "cull": not args.no_cull, "tile": args.tile or 8,
-                       "tile_order": "unchanged view: longest tiles first, from the wave durations of earlier frames of that view "
+                       "tile_order": "blocks of 16x16 tiles, longest tile first, from the wave durations of the previous launches "
                                      "(scheduling only; rt_scene_set_tile_order); see grid_order" if args.tile_order else "grid order",
                        "parallelism": f"{BLOCK}-row blocks round-robin x{world} + 1 RCCL gather per frame of "
                                       f"{24 if rgb24 else 32}-bit pixels (overlapped with the next frame's kernel)"

@@ -137,15 +137,17 @@ struct ConeSlot {
 
 #define RT_ORDER_SLOTS 4
 #define RT_ORDER_EVERY 32            // an unchanged view: the order is sorted again from fresh durations every so many launches
-#define RT_ORDER_STATIC_LAUNCHES 4   // ... and for the first time once the view has been the same for this many
+#define RT_ORDER_MOVING 3            // a view that keeps changing: every so many
 struct TileOrder {
     int key[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // tile width, frame width / height, y0, y1, local rows, interleave
                                                   // count / index / rows, and which kernel: cull, mode, samples
-    unsigned *cost = nullptr, *perm = nullptr;  // one allocation: [cap] durations, [cap] order
-    size_t cap = 0;
-    int n = 0, tiles_x = 0;
+    unsigned *cost = nullptr, *perm = nullptr, *bkey = nullptr, *start = nullptr;   // one allocation: [cap] durations, [cap] order,
+                                                                                      // [nb_cap] block keys, [nb_cap] block starts
+    size_t cap = 0, nb_cap = 0;
+    int n = 0, tiles_x = 0, tiles_y = 0, nb = 0;
     float view[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // camera and sphere list the last launch saw
     int same_view = 0;                           // consecutive launches of that view so far
+    int since_sort = 0;                          // launches (all of which recorded durations) since the order was sorted / reset
     bool have_perm = false;
     unsigned long long last_use = 0;
 };
@@ -1176,21 +1178,20 @@ int rt_scene_prepare_static(rt_scene *s, const rt_frame_desc *fd, hipStream_t st
     return rt_scene_sync_aux(s);
 }
 
-// The frame kernel records every tile's wave duration (two s_memtime and one store per wave: free). While the view
-// -- camera and sphere list -- stays what it was, the tiles are sorted "longest first" from the previous launch's
-// durations (one workgroup on the launching stream, ~80 us: after 4, 8, 16, 32, 64, ... launches of the unchanged
-// view) and the launches start their tiles in that order. A view that changes renders in grid order: the expensive
-// tiles move by several tiles per camera step, and an order one step old is worth nothing (measured: 3 % WORSE than
-// grid order, which at least keeps neighbouring tiles together; tools/tile_order_sim.py). Scheduling only -- every
-// tile is rendered once, by the same instructions. Ordering against frames in flight: the sort waits (on the device)
-// for every frame launched so far, which read the old order; frames launched afterwards on other streams wait for
-// the sort's event.
+// The frame kernel records every tile's wave duration (two s_memtime and one store per wave: free). From the
+// previous launch's durations the blocks of 16 x 16 tiles are sorted "longest tile first" (one workgroup on the
+// launching stream, rt_tables.hip) and the launches start their tiles in that order: sorted again after 2, 4, 8, 16,
+// 32, 64, 96, ... launches of an unchanged view (camera, sphere list), every RT_ORDER_MOVING launches while the view
+// keeps changing. Scheduling only -- every tile is rendered once, by the same instructions. Ordering against frames
+// in flight: the sort waits (on the device) for every frame launched so far, which read the old order; frames launched
+// afterwards on other streams wait for the sort's event.
 static int rt_scene_prepare_tile_order(rt_scene *s, const RtKernelChoice &kc, RtFrameConsts *fc, hipStream_t stream)
 {
     const int tile_w = kc.tile, th = 64 / tile_w;
     const int tiles_x = (fc->width + tile_w - 1) / tile_w, tiles_y = (fc->local_rows + th - 1) / th;
-    if (tiles_x > 0xffff || tiles_y > 0xffff) return RT_OK;            // does not fit the packed form: grid order
-    const int n = tiles_x * tiles_y;
+    const int nbx = (tiles_x + RT_TILE_ORDER_BLOCK - 1) / RT_TILE_ORDER_BLOCK, nby = (tiles_y + RT_TILE_ORDER_BLOCK - 1) / RT_TILE_ORDER_BLOCK;
+    if (tiles_x > 0xffff || tiles_y > 0xffff || (long long)nbx * nby > RT_TILE_ORDER_MAX_BLOCKS) return RT_OK;   // grid order
+    const int n = tiles_x * tiles_y, nb = nbx * nby;
     const int key[12] = {tile_w, fc->width, fc->height, fc->y0, fc->y1, fc->local_rows, fc->il_count, fc->il_index, fc->il_rows,
                          kc.cull, kc.mode, fc->spp};
     // what the durations depend on from frame to frame: the view and the sphere list
@@ -1210,44 +1211,53 @@ static int rt_scene_prepare_tile_order(rt_scene *s, const RtKernelChoice &kc, Rt
         t = lru;
         int rc = stream_wait_all_frames(s, stream);   // frames that still write into the slot's old arrays
         if (rc != RT_OK) return rc;
-        if ((size_t)n > t->cap) {
+        if ((size_t)n > t->cap || (size_t)nb > t->nb_cap) {
             rc = rt_scene_quiesce(s);                  // re-allocation: nothing may still use the old arrays
             if (rc != RT_OK) return rc;
             if (t->cost) RT_HIP(hipFree(t->cost));
-            t->cost = t->perm = nullptr;
-            t->cap = 0;
-            const size_t cap = ((size_t)n + 3) & ~(size_t)3;     // the sort reads four at a time
-            RT_HIP(hipMalloc((void **)&t->cost, sizeof(unsigned) * 2 * cap));
-            t->cap = cap;
+            t->cost = t->perm = t->bkey = t->start = nullptr;
+            t->cap = t->nb_cap = 0;
+            RT_HIP(hipMalloc((void **)&t->cost, sizeof(unsigned) * (2 * (size_t)n + 2 * (size_t)nb)));
+            t->cap = (size_t)n;
+            t->nb_cap = (size_t)nb;
         }
         t->perm = t->cost + t->cap;
+        t->bkey = t->perm + t->cap;
+        t->start = t->bkey + t->nb_cap;
         RT_HIP(hipMemsetAsync(t->cost, 0, sizeof(unsigned) * t->cap, stream));
         memcpy(t->key, key, sizeof key);
         memcpy(t->view, view, sizeof view);
         t->n = n;
+        t->nb = nb;
         t->tiles_x = tiles_x;
+        t->tiles_y = tiles_y;
         t->same_view = 0;
+        t->since_sort = 0;
         t->have_perm = false;
         if (!s->order_built) RT_HIP(hipEventCreateWithFlags(&s->order_built, hipEventDisableTiming));
         RT_HIP(hipEventRecord(s->order_built, stream));   // launches on other streams: after the reset
         s->order_pending = true;
-    } else if (memcmp(t->view, view, sizeof view) != 0) {
-        memcpy(t->view, view, sizeof view);
-        t->same_view = 0;                              // this launch and the next ones: grid order
-        t->have_perm = false;
     } else {
-        // launches of this view so far: t->same_view, all of which recorded durations; sort after 4, 8, 16, 32, 64, 96, ...
+        if (memcmp(t->view, view, sizeof view) != 0) {
+            memcpy(t->view, view, sizeof view);
+            t->same_view = 0;
+        }
+        // launches of this view so far: t->same_view; launches since the last sort: t->since_sort (all recorded durations)
         const int k = t->same_view;
-        if (k >= RT_ORDER_STATIC_LAUNCHES && ((k & (k - 1)) == 0 || k % RT_ORDER_EVERY == 0)) {
+        const bool due = k == 0 ? t->since_sort >= (t->have_perm ? RT_ORDER_MOVING : 1)                 // a view that changes
+                                : (k >= 2 && ((k & (k - 1)) == 0 || k % RT_ORDER_EVERY == 0)) || !t->have_perm;
+        if (due && t->since_sort >= 1) {
             int rc = stream_wait_all_frames(s, stream);
             if (rc != RT_OK) return rc;
-            RT_HIP(rt_tile_order_launch(t->cost, t->perm, t->n, t->tiles_x, stream));
+            RT_HIP(rt_tile_order_launch(t->cost, t->bkey, t->start, t->perm, t->tiles_x, t->tiles_y, stream));
             if (!s->order_built) RT_HIP(hipEventCreateWithFlags(&s->order_built, hipEventDisableTiming));
             RT_HIP(hipEventRecord(s->order_built, stream));
             s->order_pending = true;
             t->have_perm = true;
+            t->since_sort = 0;
         }
     }
+    t->since_sort++;
     t->same_view++;
     t->last_use = ++s->order_clock;
     fc->tile_cost = t->cost;

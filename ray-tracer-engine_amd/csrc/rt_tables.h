@@ -21,7 +21,13 @@ hipError_t rt_eye_cones_launch(const float4 *tab, int n, const float org[3], flo
 // (const float4 *tab, int n, float ox, float oy, float oz, float4 *out).
 void rt_eye_cones_kernel_config(int n, int threads, const void **func, dim3 *grid, dim3 *block, unsigned *lds_bytes);
 
-// Order of the tiles of a launch, longest first (RtFrameConsts::tile_perm): a counting sort of `n` tiles by the wave
-// durations of an earlier frame (cost[], shader clocks; 0 = never rendered) into perm[] = (tile_y << 16) | tile_x,
-// one workgroup on `stream`. Always a permutation of the n tiles, whatever cost[] holds.
-hipError_t rt_tile_order_launch(const unsigned *cost, unsigned *perm, int n, int tiles_x, hipStream_t stream);
+// Order of the tiles of a launch (RtFrameConsts::tile_perm): blocks of RT_TILE_ORDER_BLOCK x RT_TILE_ORDER_BLOCK tiles,
+// the block with the longest tile first (cost[tile]: wave durations of the previous launch, shader clocks; 0 = never
+// rendered), tiles row-major inside a block; perm[] = (tile_y << 16) | tile_x. Three small kernels on `stream` (the
+// blocks' longest tiles into key[]; the blocks sorted, where each starts into start[]; a thread per tile writes perm[]).
+// Always a permutation of the tiles, whatever cost[] holds. At most RT_TILE_ORDER_MAX_BLOCKS blocks; key[], start[]:
+// one unsigned per block.
+#define RT_TILE_ORDER_BLOCK 16
+#define RT_TILE_ORDER_MAX_BLOCKS 4096
+hipError_t rt_tile_order_launch(const unsigned *cost, unsigned *key, unsigned *start, unsigned *perm, int tiles_x, int tiles_y,
+                                hipStream_t stream);

@@ -442,69 +442,110 @@ hipError_t rt_eye_cones_launch(const float4 *tab, int n, const float org[3], flo
 }
 
 // ---------------------------------------------------------------------------
-// tile order of a launch: longest tiles first
+// tile order of a launch: the blocks with the longest tiles first
 // ---------------------------------------------------------------------------
 // A launch ends when its slowest wave does. Tiles take 6 ... 90 us (a tile that walks the shadow samples of three
 // lights for several groups of pixels against one that is fully occluded), and in row-major order the expensive ones
 // of the last rows start last: the SIMDs drain for tens of microseconds -- 45 us per launch at C3, 12 % of a frame
-// and half of an eighth of it. Started longest-first (the classic LPT rule) the launch ends with the cheap ones.
-// The durations come from the frame kernel itself (RtFrameConsts::tile_cost), recorded for the same view.
-#define RT_ORDER_BUCKETS 1024
-// 32 buckets per octave of the duration (exponent and five mantissa bits of the value as a float), whatever the
-// magnitude: 3 % resolution from 1 to 2^32 clocks, no pass over the data to find its range
+// and half of an eighth of it. So the frame is cut into blocks of 16 x 16 tiles, the blocks are started in the order
+// of their longest tile (wave durations of the previous launch, RtFrameConsts::tile_cost), tiles row-major inside a
+// block. Blocks rather than single tiles: neighbouring tiles keep running together (textures, tables in cache) --
+// on the GPU the block order beats the per-tile order even with durations of the very same view, 0.340 against 0.356 ms
+// at C3 -- and a camera step, which moves the expensive tiles by several tiles and makes a per-tile order worthless,
+// costs a block order 1 % (tools/tile_order_probe.py).
+#define RT_ORDER_BUCKETS 256
+#define RT_ORDER_BLOCK 16
+// eight buckets per octave of the duration (exponent and three mantissa bits of the value as a float)
 __device__ __forceinline__ unsigned tile_cost_bucket(unsigned c)
 {
-    const unsigned b = __float_as_uint((float)c) >> 18;      // 0 for c = 0; 127 << 5 for c = 1
-    return b >= (127u << 5) ? min(b - (127u << 5), (unsigned)RT_ORDER_BUCKETS - 1u) : 0u;
+    const unsigned b = __float_as_uint((float)c) >> 20;      // 0 for c = 0; 127 << 3 for c = 1
+    return b >= (127u << 3) ? min(b - (127u << 3), (unsigned)RT_ORDER_BUCKETS - 1u) : 0u;
 }
 
-__global__ __launch_bounds__(1024) void rt_tile_order_kernel(const unsigned *__restrict__ cost, unsigned *__restrict__ perm, int n,
-                                                             int tiles_x)
+// The longest tile of every block: a workgroup per block, a thread per tile.
+__global__ __launch_bounds__(256) void rt_tile_order_keys_kernel(const unsigned *__restrict__ cost, unsigned *__restrict__ key, int nbx,
+                                                                 int tiles_x, int tiles_y)
 {
-    __shared__ unsigned hist[RT_ORDER_BUCKETS];
+    __shared__ unsigned m;
+    if (threadIdx.x == 0) m = 0;
+    __syncthreads();
+    const int b = blockIdx.x;
+    const int tx = (b % nbx) * RT_ORDER_BLOCK + (int)(threadIdx.x % RT_ORDER_BLOCK), ty = (b / nbx) * RT_ORDER_BLOCK + (int)(threadIdx.x / RT_ORDER_BLOCK);
+    unsigned c = (tx < tiles_x && ty < tiles_y) ? cost[ty * tiles_x + tx] : 0u;
+    for (int o = 32; o > 0; o >>= 1) c = max(c, (unsigned)__shfl_xor((int)c, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(&m, c);
+    __syncthreads();
+    if (threadIdx.x == 0) key[b] = m;
+}
+
+// Inclusive prefix sums of a[0..n) in LDS (n <= 4 * 1024), all 1024 threads of the workgroup; tmp: as large as a.
+__device__ void scan_inclusive_lds(unsigned *a, unsigned *tmp, int n)
+{
+    unsigned *src = a, *dst = tmp;
+    for (int o = 1; o < n; o <<= 1) {
+        for (int i = threadIdx.x; i < n; i += 1024) dst[i] = src[i] + (i >= o ? src[i - o] : 0u);
+        __syncthreads();
+        unsigned *t = src; src = dst; dst = t;
+    }
+    if (src != a) {
+        for (int i = threadIdx.x; i < n; i += 1024) a[i] = src[i];
+        __syncthreads();
+    }
+}
+
+// Sorts the blocks by their keys, longest first (counting sort, one workgroup), and writes where each block's tiles
+// start in the order.
+__global__ __launch_bounds__(1024) void rt_tile_order_sort_kernel(const unsigned *__restrict__ key, unsigned *__restrict__ start, int nbx,
+                                                                  int nby, int tiles_x, int tiles_y)
+{
+    __shared__ unsigned at_rank[RT_TILE_ORDER_MAX_BLOCKS];  // the block at each place of the order
+    __shared__ unsigned sizes[RT_TILE_ORDER_MAX_BLOCKS];    // tiles of the block at each place, then their prefix sums
+    __shared__ unsigned tmp[RT_TILE_ORDER_MAX_BLOCKS];
+    __shared__ unsigned hist[RT_ORDER_BUCKETS], hsum[RT_ORDER_BUCKETS], htmp[RT_ORDER_BUCKETS];
     const int tid = threadIdx.x;
+    const int nb = nbx * nby;
     for (int b = tid; b < RT_ORDER_BUCKETS; b += 1024) hist[b] = 0;
     __syncthreads();
-    // four tiles per load (the array is padded to a multiple of four)
-    const uint4 *cost4 = reinterpret_cast<const uint4 *>(cost);
-    const int n4 = (n + 3) >> 2;
-    for (int q = tid; q < n4; q += 1024) {
-        const uint4 c = cost4[q];
-        const int i = q << 2;
-        atomicAdd(&hist[tile_cost_bucket(c.x)], 1u);
-        if (i + 1 < n) atomicAdd(&hist[tile_cost_bucket(c.y)], 1u);
-        if (i + 2 < n) atomicAdd(&hist[tile_cost_bucket(c.z)], 1u);
-        if (i + 3 < n) atomicAdd(&hist[tile_cost_bucket(c.w)], 1u);
+    for (int b = tid; b < nb; b += 1024) atomicAdd(&hist[tile_cost_bucket(key[b])], 1u);
+    __syncthreads();
+    // where each bucket starts, the longest durations first: prefix sums over the buckets in descending order
+    for (int k = tid; k < RT_ORDER_BUCKETS; k += 1024) hsum[k] = hist[RT_ORDER_BUCKETS - 1 - k];
+    __syncthreads();
+    scan_inclusive_lds(hsum, htmp, RT_ORDER_BUCKETS);
+    for (int k = tid; k < RT_ORDER_BUCKETS; k += 1024) hist[RT_ORDER_BUCKETS - 1 - k] = hsum[k] - hist[RT_ORDER_BUCKETS - 1 - k];
+    __syncthreads();
+    for (int b = tid; b < nb; b += 1024) at_rank[atomicAdd(&hist[tile_cost_bucket(key[b])], 1u)] = (unsigned)b;
+    __syncthreads();
+    // where each block's tiles start (blocks at the right and lower edge are smaller)
+    for (int r = tid; r < nb; r += 1024) {
+        const unsigned b = at_rank[r];
+        const int bx = (int)(b % (unsigned)nbx), by = (int)(b / (unsigned)nbx);
+        sizes[r] = (unsigned)(min(RT_ORDER_BLOCK, tiles_x - bx * RT_ORDER_BLOCK) * min(RT_ORDER_BLOCK, tiles_y - by * RT_ORDER_BLOCK));
     }
     __syncthreads();
-    if (tid == 0) {   // where each bucket starts, the longest durations first
-        unsigned at = 0;
-        for (int b = RT_ORDER_BUCKETS - 1; b >= 0; --b) {
-            const unsigned c = hist[b];
-            hist[b] = at;
-            at += c;
-        }
-    }
-    __syncthreads();
-    // tiles of one bucket keep (roughly: the atomics of one pass arrive in index order) their row-major order
-    for (int q = tid; q < n4; q += 1024) {
-        const uint4 c = cost4[q];
-        const unsigned cs[4] = {c.x, c.y, c.z, c.w};
-        const int i0 = q << 2;
-        unsigned ty = (unsigned)i0 / (unsigned)tiles_x, tx = (unsigned)i0 - ty * (unsigned)tiles_x;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (i0 + j < n) {
-                const unsigned pos = atomicAdd(&hist[tile_cost_bucket(cs[j])], 1u);
-                perm[pos] = (ty << 16) | tx;
-            }
-            if (++tx == (unsigned)tiles_x) { tx = 0; ++ty; }
-        }
-    }
+    scan_inclusive_lds(sizes, tmp, nb);
+    for (int r = tid; r < nb; r += 1024) start[at_rank[r]] = r ? sizes[r - 1] : 0u;
 }
 
-hipError_t rt_tile_order_launch(const unsigned *cost, unsigned *perm, int n, int tiles_x, hipStream_t stream)
+// perm[] from the blocks' starting places: a thread per tile, tiles row-major inside their block
+__global__ __launch_bounds__(256) void rt_tile_order_expand_kernel(const unsigned *__restrict__ start, unsigned *__restrict__ perm, int n,
+                                                                   int tiles_x, int nbx)
 {
-    hipLaunchKernelGGL(rt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, cost, perm, n, tiles_x);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned ty = (unsigned)i / (unsigned)tiles_x, tx = (unsigned)i - ty * (unsigned)tiles_x;
+    const unsigned bx = tx / RT_ORDER_BLOCK, by = ty / RT_ORDER_BLOCK;
+    const unsigned bw = (unsigned)min(RT_ORDER_BLOCK, tiles_x - (int)bx * RT_ORDER_BLOCK);
+    perm[start[by * nbx + bx] + (ty % RT_ORDER_BLOCK) * bw + (tx % RT_ORDER_BLOCK)] = (ty << 16) | tx;
+}
+
+hipError_t rt_tile_order_launch(const unsigned *cost, unsigned *key, unsigned *start, unsigned *perm, int tiles_x, int tiles_y,
+                                hipStream_t stream)
+{
+    const int nbx = (tiles_x + RT_ORDER_BLOCK - 1) / RT_ORDER_BLOCK, nby = (tiles_y + RT_ORDER_BLOCK - 1) / RT_ORDER_BLOCK;
+    const int n = tiles_x * tiles_y;
+    hipLaunchKernelGGL(rt_tile_order_keys_kernel, dim3(nbx * nby), dim3(256), 0, stream, cost, key, nbx, tiles_x, tiles_y);
+    hipLaunchKernelGGL(rt_tile_order_sort_kernel, dim3(1), dim3(1024), 0, stream, key, start, nbx, nby, tiles_x, tiles_y);
+    hipLaunchKernelGGL(rt_tile_order_expand_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, start, perm, n, tiles_x, nbx);
     return hipGetLastError();
 }

@@ -819,8 +819,9 @@ def test_fast_mode_stays_within_the_tolerance_away_from_flips(rt, gpu):
 
 @pytest.mark.gpu
 def test_tile_order_changes_the_schedule_not_the_pixels(rt, gpu):
-    """rt_scene_set_tile_order: longest-first launches (sorted from wave durations the kernel records, after 4, 8,
-    16, ... launches of an unchanged view) render the same bits as grid-order launches -- whole frame, a row band,
+    """rt_scene_set_tile_order: launches whose tiles start in the order the library sorts from the wave durations the
+    kernel records (blocks of 16 x 16 tiles, longest first; re-sorted after 1, 2, 4, 8, ... launches of an unchanged view
+    and every third launch of a moving one) render the same bits as grid-order launches -- whole frame, a row band,
     interleaved rows, two streams sharing the scene, a camera that rests and moves, layouts evicting each other."""
     import torch
     w, h = 640, 360
