@@ -1121,16 +1121,15 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
 
     // which tile: the workgroup's own, or (one-wave workgroups) the one the frame's tile order puts at this place
     unsigned blk_x = blockIdx.x, blk_y = blockIdx.y;
-    unsigned t_start = 0, cost_idx = 0;
-    if (!TABLDS && (fc.tile_perm || fc.tile_cost)) {
-        const unsigned tiles_x = (unsigned)(fc.width + TW - 1) / (unsigned)TW;   // = gridDim.x of a one-wave-workgroup launch
+    unsigned t_start = 0;
+    const unsigned tiles_x = (unsigned)(fc.width + TW - 1) / (unsigned)TW;   // = gridDim.x of a one-wave-workgroup launch
+    if (!TABLDS) {
         if (fc.tile_perm) {
             const unsigned p = fc.tile_perm[blockIdx.y * tiles_x + blockIdx.x];
             blk_x = p & 0xffffu;
             blk_y = p >> 16;
         }
-        cost_idx = blk_y * tiles_x + blk_x;
-        t_start = (unsigned)__builtin_amdgcn_s_memtime();
+        if (fc.tile_cost) t_start = (unsigned)__builtin_amdgcn_s_memtime();
     }
     const int tile_x = (blk_x * WGX + (wave % WGX)) * TW;
     // local row -> global row: a contiguous band, or row blocks dealt round-robin
@@ -1897,7 +1896,7 @@ __global__ __launch_bounds__(64 * (TABLDS ? RT_WAVES_PER_WG : 1), (FEAT == 2) ? 
     if (!TABLDS && o_cost) {   // this tile's wave duration, for the order of later frames (a plain store: an atomic maximum
         // per block of tiles here, 256 waves ending together on one address, slowed the whole launch down by 3 %)
         const unsigned dt = (unsigned)__builtin_amdgcn_s_memtime() - t_start;
-        if (lane == 0) o_cost[cost_idx] = dt;
+        if (lane == 0) o_cost[blk_y * tiles_x + blk_x] = dt;
     }
 
     phase(3, true);
