@@ -137,7 +137,9 @@ struct ConeSlot {
 
 #define RT_ORDER_SLOTS 4
 #define RT_ORDER_EVERY 32            // an unchanged view: the order is sorted again from fresh durations every so many launches
+#ifndef RT_ORDER_MOVING
 #define RT_ORDER_MOVING 3            // a view that keeps changing: every so many
+#endif
 struct TileOrder {
     int key[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // tile width, frame width / height, y0, y1, local rows, interleave
                                                   // count / index / rows, and which kernel: cull, mode, samples
