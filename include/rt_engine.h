@@ -342,8 +342,8 @@ int rt_scene_render(rt_scene *s, const rt_frame_desc *fd, void *stream);
  * unchanged view (camera, sphere list) and layout (frame size, rows, tile shape), every third launch while the view
  * keeps changing. A launch then ends with its cheap tiles instead of draining the SIMDs behind a few expensive ones
  * (C3: 0.38 -> 0.35 ms per frame, an eighth of the frame 0.085 -> 0.071 ms; a moving camera 0.398 -> 0.381 ms).
- * 0: grid order. Scheduling only: the pixels are the same bits either way. Graph replays and table_lds launches
- * always run in grid order.                                                                                      */
+ * 0: grid order. Scheduling only: the pixels are the same bits either way. A frame graph sorts its own order at the
+ * head of every replay (from the durations of the previous one); table_lds launches always run in grid order.     */
 int rt_scene_set_tile_order(rt_scene *s, int mode);
 
 /* hipGraph-captured frame loop (config C4): `passes` progressive sample passes

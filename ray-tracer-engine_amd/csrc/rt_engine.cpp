@@ -1317,6 +1317,8 @@ extern "C" int rt_scene_render(rt_scene *s, const rt_frame_desc *fd, void *strea
     return rt_scene_note_launch(s, stream, slot);
 }
 
+int rt_scene_tile_order_mode(const rt_scene *s) { return s->tile_order_mode; }
+
 extern "C" int rt_scene_set_tile_order(rt_scene *s, int mode)
 {
     if (!s || (mode != 0 && mode != 1)) {

@@ -3,7 +3,10 @@
 // malloc -> H2D -> launch -> sync -> free sequence (/root/reference/kernel.cu:1762-1792)
 // with a graph built once:
 //
-//   [eye-cone build]  ->  [sample pass 0] -> ... -> [sample pass p-1]  ->  [copy to the present buffer]
+//   [eye-cone build]  ->  [tile order: keys, sort, expand]  ->  [sample pass 0] -> ... -> [sample pass p-1]  ->  [copy to the present buffer]
+//
+// (the tile order -- blocks of 16 x 16 tiles, longest tile first, DESIGN.md section 4d -- is sorted at the head of every
+// replay from the wave durations the passes of the previous replay recorded into the graph's own arrays)
 //
 // The nodes are added explicitly (no stream capture), so each kernel node's by-value frame
 // uniforms can be replaced in the instantiated graph: a camera move -- the reference moves
@@ -42,6 +45,11 @@ struct rt_frame_graph {
     size_t cones_cap = 0;            // float4 units
     bool cones_on_device = false;    // built by the graph's build node (else by the host at (re)build time)
     unsigned long long epoch = 0;    // rt_scene_epoch() the nodes were built against
+    // launch order of the passes' tiles (rt_scene_set_tile_order): [n] durations, [n] order, [nb] block keys, [nb] block starts
+    unsigned *order_buf = nullptr;
+    size_t order_cap = 0;            // unsigneds
+    unsigned *o_cost = nullptr, *o_perm = nullptr, *o_key = nullptr, *o_start = nullptr;
+    bool order_on = false;
 };
 
 static void release_graph(rt_frame_graph *g)
@@ -73,6 +81,10 @@ static int fill_arguments(rt_frame_graph *g, bool with_cones)
         const rt_frame_desc fd = pass_desc(g, p);
         const int rc = rt_build_frame_consts(g->scene, &fd, with_cones ? g->cones : nullptr, &g->fc[p]);
         if (rc != RT_OK) return rc;
+        if (g->order_on) {
+            g->fc[p].tile_perm = g->o_perm;
+            g->fc[p].tile_cost = g->o_cost;
+        }
     }
     return RT_OK;
 }
@@ -110,6 +122,37 @@ static int build_graph(rt_frame_graph *g, hipStream_t stream)
             if (rc != RT_OK) return rc;
         }
     }
+    // the passes' launch order: all passes render the same rows with the same tile shape
+    int tiles_x = 0, tiles_y = 0;
+    g->order_on = false;
+    {
+        const rt_frame_desc fd0 = pass_desc(g, 0);
+        RtKernelChoice kc0;
+        RtFrameConsts fc0;
+        int rc0 = rt_frame_kernel_choice(s, &fd0, &kc0);
+        if (rc0 == RT_OK) rc0 = rt_build_frame_consts(s, &fd0, nullptr, &fc0);
+        if (rc0 != RT_OK) return rc0;
+        tiles_x = (fc0.width + kc0.tile - 1) / kc0.tile;
+        tiles_y = (fc0.local_rows + 64 / kc0.tile - 1) / (64 / kc0.tile);
+        const long long nb = (long long)((tiles_x + RT_TILE_ORDER_BLOCK - 1) / RT_TILE_ORDER_BLOCK) * ((tiles_y + RT_TILE_ORDER_BLOCK - 1) / RT_TILE_ORDER_BLOCK);
+        if (rt_scene_tile_order_mode(s) != 0 && !kc0.table_lds && fc0.local_rows > 0 && tiles_x <= 0xffff && tiles_y <= 0xffff &&
+            nb <= RT_TILE_ORDER_MAX_BLOCKS) {
+            const size_t n = (size_t)tiles_x * (size_t)tiles_y, need = 2 * n + 2 * (size_t)nb;
+            if (need > g->order_cap) {
+                if (g->order_buf) RT_HIP(hipFree(g->order_buf));
+                g->order_buf = nullptr;
+                g->order_cap = 0;
+                RT_HIP(hipMalloc((void **)&g->order_buf, sizeof(unsigned) * need));
+                g->order_cap = need;
+            }
+            g->o_cost = g->order_buf;
+            g->o_perm = g->o_cost + n;
+            g->o_key = g->o_perm + n;
+            g->o_start = g->o_key + nb;
+            RT_HIP(hipMemset(g->o_cost, 0, sizeof(unsigned) * n));   // no durations yet: the first replay sorts zeros (any order)
+            g->order_on = true;
+        }
+    }
     int rc = fill_arguments(g, want_cones);
     if (rc != RT_OK) return rc;
     g->spheres = rt_scene_sphere_table(s);
@@ -130,6 +173,29 @@ static int build_graph(rt_frame_graph *g, hipStream_t stream)
         RT_HIP(hipGraphAddKernelNode(&g->build_node, g->graph, nullptr, 0, &g->build_params));
         g->build_params.kernelParams = nullptr;   // `args` is a local: re-pointed on every update
         prev = g->build_node;
+    }
+    if (g->order_on) {   // keys -> sort -> expand, from the durations of the previous replay
+        const void *func[3];
+        dim3 grid[3], block[3];
+        rt_tile_order_kernel_configs(tiles_x, tiles_y, func, grid, block);
+        int nbx = (tiles_x + RT_TILE_ORDER_BLOCK - 1) / RT_TILE_ORDER_BLOCK, nby = (tiles_y + RT_TILE_ORDER_BLOCK - 1) / RT_TILE_ORDER_BLOCK;
+        int n = tiles_x * tiles_y;
+        const unsigned *c_cost = g->o_cost, *c_key = g->o_key, *c_start = g->o_start;
+        void *a0[] = {&c_cost, &g->o_key, &nbx, &tiles_x, &tiles_y};
+        void *a1[] = {&c_key, &g->o_start, &nbx, &nby, &tiles_x, &tiles_y};
+        void *a2[] = {&c_start, &g->o_perm, &n, &tiles_x, &nbx};
+        void **args[3] = {a0, a1, a2};
+        for (int k = 0; k < 3; ++k) {
+            hipKernelNodeParams kp;
+            memset(&kp, 0, sizeof kp);
+            kp.func = const_cast<void *>(func[k]);
+            kp.gridDim = grid[k];
+            kp.blockDim = block[k];
+            kp.kernelParams = args[k];
+            hipGraphNode_t node;
+            RT_HIP(hipGraphAddKernelNode(&node, g->graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp));
+            prev = node;
+        }
     }
     for (int p = 0; p < g->passes; ++p) {
         const rt_frame_desc fd = pass_desc(g, p);
@@ -253,5 +319,6 @@ extern "C" void rt_graph_destroy(rt_frame_graph *g)
     if (g->scene) (void)rt_scene_quiesce(g->scene);
     release_graph(g);
     if (g->cones) (void)hipFree(g->cones);
+    if (g->order_buf) (void)hipFree(g->order_buf);
     delete g;
 }

@@ -37,6 +37,7 @@ const float4 *rt_scene_sphere_table(const rt_scene *s);
 int rt_scene_sphere_count(const rt_scene *s);
 unsigned long long rt_scene_epoch(const rt_scene *s);
 bool rt_scene_wants_eye_cones(const rt_scene *s, const float org[3]);
+int rt_scene_tile_order_mode(const rt_scene *s);   // rt_scene_set_tile_order
 int rt_scene_build_eye_cones_host(rt_scene *s, const float org[3], float4 *buf, hipStream_t stream);
 
 // launchers of rt_kernels.hip

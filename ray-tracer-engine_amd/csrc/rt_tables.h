@@ -31,3 +31,4 @@ void rt_eye_cones_kernel_config(int n, int threads, const void **func, dim3 *gri
 #define RT_TILE_ORDER_MAX_BLOCKS 4096
 hipError_t rt_tile_order_launch(const unsigned *cost, unsigned *key, unsigned *start, unsigned *perm, int tiles_x, int tiles_y,
                                 hipStream_t stream);
+void rt_tile_order_kernel_configs(int tiles_x, int tiles_y, const void *func[3], dim3 grid[3], dim3 block[3]);

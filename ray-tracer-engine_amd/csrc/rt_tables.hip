@@ -549,3 +549,15 @@ hipError_t rt_tile_order_launch(const unsigned *cost, unsigned *key, unsigned *s
     hipLaunchKernelGGL(rt_tile_order_expand_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, start, perm, n, tiles_x, nbx);
     return hipGetLastError();
 }
+
+// The same three launches as graph kernel nodes (rt_graph.cpp): functions and geometries; the arguments are
+// keys: (const unsigned *cost, unsigned *key, int nbx, int tiles_x, int tiles_y)
+// sort: (const unsigned *key, unsigned *start, int nbx, int nby, int tiles_x, int tiles_y)
+// expand: (const unsigned *start, unsigned *perm, int n, int tiles_x, int nbx)
+void rt_tile_order_kernel_configs(int tiles_x, int tiles_y, const void *func[3], dim3 grid[3], dim3 block[3])
+{
+    const int nbx = (tiles_x + RT_ORDER_BLOCK - 1) / RT_ORDER_BLOCK, nby = (tiles_y + RT_ORDER_BLOCK - 1) / RT_ORDER_BLOCK;
+    func[0] = (const void *)rt_tile_order_keys_kernel;   grid[0] = dim3(nbx * nby); block[0] = dim3(256);
+    func[1] = (const void *)rt_tile_order_sort_kernel;   grid[1] = dim3(1); block[1] = dim3(1024);
+    func[2] = (const void *)rt_tile_order_expand_kernel; grid[2] = dim3((tiles_x * tiles_y + 255) / 256); block[2] = dim3(256);
+}
