@@ -22,3 +22,6 @@ echo "configs done"
 bash tools/ablate_pmc.sh > $OUT/ablation_pmc.txt 2>&1 || exit 11
 RT_ENGINE_LIB=$PWD/ray-tracer-engine_amd/csrc/librt_engine_tuning.so python3 tools/mesh_ablate.py > $OUT/mesh_ablate.json 2>/dev/null || exit 12
 echo "ablation done"
+python3 tools/tile_order_experiment.py > $OUT/tile_order.json 2>/dev/null || exit 13
+python3 bench.py --no-cpu-baseline --tile-order 0 > $OUT/bench_tile_order0.json 2>/dev/null || exit 14
+echo "launch order done"
