@@ -64,6 +64,10 @@ def parse():
     ap.add_argument("--table-lds", action="store_true", help="stage the whole sphere table in LDS per workgroup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the moving-camera / pipelined / update() legs")
+    ap.add_argument("--no-preroll", action="store_true",
+                    help="skip the untimed pre-roll that lets the GPU reach its clock under the workload before the timed region")
+    ap.add_argument("--smi-clocks", type=int, choices=(0, 1), default=1,
+                    help="1: fall back to rocm-smi (outside every timed region) when sysfs has no clock table")
     ap.add_argument("--cpu-band-stride", type=int, default=8,
                     help="CPU baseline renders every k-th 8-row band of the frame")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline")
@@ -159,8 +163,75 @@ def committed_pmc(args, world):
         return None
 
 
-def timed_loop(step, steps, warmup, sync, world):
+def read_clocks(fast_only=False):
+    """Shader / memory clock of the GPU this process renders on, as the driver reports them at this moment
+    ("record actual clocks with each run"). Called while launches are in flight, so that the
+    reading is the clock under this workload and not the idle one. sysfs first (no subprocess), rocm-smi second;
+    whatever cannot be read is None -- the bench never fails over it."""
+    import glob
+    import re
+    import subprocess
+    out = {"sclk_mhz": None, "mclk_mhz": None, "source": None}
+    try:
+        idx = torch.cuda.current_device()
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        # the idx-th card that has a DPM table (render nodes without one are not GPUs of this kind)
+        if idx < len(cards):
+            base = os.path.dirname(cards[idx])
+            for key, name in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
+                with open(os.path.join(base, name)) as f:
+                    for line in f:
+                        m = re.search(r"(\d+)\s*[Mm][Hh]z\s*\*", line)
+                        if m:
+                            out[key] = int(m.group(1))
+            if out["sclk_mhz"] is not None:
+                out["source"] = "sysfs pp_dpm_sclk/pp_dpm_mclk (level marked current)"
+                return out
+    except Exception:
+        pass
+    if fast_only:       # inside a timed region: never start a subprocess there
+        return out
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(torch.cuda.current_device()), "--showclocks", "--json"],
+                           capture_output=True, text=True, timeout=20)
+        d = json.loads(r.stdout[r.stdout.index("{"):])
+        card = next(iter(d.values()))
+        for k, v in card.items():
+            m = re.search(r"\((\d+)\s*[Mm][Hh]z\)", str(v))
+            if not m:
+                continue
+            if "sclk" in k.lower() and out["sclk_mhz"] is None:
+                out["sclk_mhz"] = int(m.group(1))
+            if "mclk" in k.lower() and out["mclk_mhz"] is None:
+                out["mclk_mhz"] = int(m.group(1))
+        out["source"] = "rocm-smi --showclocks"
+    except Exception as e:          # no rocm-smi, no permission, ...: say so
+        out["source"] = f"unavailable ({type(e).__name__})"
+    return out
+
+
+def preroll(step, sync, reduce_max, window=10, tol=0.02, max_windows=60):
+    """Untimed launches before the timed region until the GPU has reached its clock under this workload: windows
+    of `window` frames are timed on the host until two consecutive ones agree within `tol` (a fresh box ramps its
+    shader clock over the first few hundred launches; BENCH_r02's `value` loop ran first and was 11 % slow).
+    Returns the step counter to continue from and what was observed."""
     k = 0
+    hist = []
+    for _ in range(max_windows):
+        t0 = time.perf_counter()
+        for _ in range(window):
+            step(k, None)
+            k += 1
+        sync(k)
+        hist.append(reduce_max((time.perf_counter() - t0) / window * 1e3)[0])   # every rank takes the same decision
+        if len(hist) >= 3 and abs(hist[-1] - hist[-2]) <= tol * hist[-1] and abs(hist[-2] - hist[-3]) <= tol * hist[-2]:
+            break
+    return k, {"launches": k, "window": window, "tolerance": tol, "first_window_ms": hist[0], "last_window_ms": hist[-1],
+               "windows": len(hist), "settled": len(hist) < max_windows}
+
+
+def timed_loop(step, steps, warmup, sync, world, k0=0, mid=None):
+    k = k0
     for _ in range(warmup):
         step(k, None)
         k += 1
@@ -169,8 +240,9 @@ def timed_loop(step, steps, warmup, sync, world):
     for i in range(steps):
         step(k, i)
         k += 1
+    side = mid() if mid else None      # (launches are asynchronous: this runs while the GPU works through them)
     sync(k)
-    return time.perf_counter() - t0, k
+    return time.perf_counter() - t0, k, side
 
 
 def main():
@@ -246,11 +318,16 @@ def main():
                     nonlocal frame
                     frame = roots[b].assemble()       # one index_select puts every row in place
 
-    def make_step(streams, ev, fd_of):
+    gather_end = [None, None]     # root: event to record once buffer set b's gather and assembly are on its stream
+
+    def make_step(streams, ev, fd_of, ev_g=None):
         def step(k, i):
             b = k & 1
             if world > 1:
                 finish(b, streams)             # buffer set b is free again
+                if gather_end[b] is not None:  # ... and its exchange (gather + assembly on the root) ends here in stream order
+                    gather_end[b].record(streams[b])
+                    gather_end[b] = None
             with torch.cuda.stream(streams[b]):
                 timed = i is not None and ev is not None and i % EV_EVERY == 0
                 if timed:
@@ -258,6 +335,9 @@ def main():
                 scene.render_raw(fd_of(k, b), streams[b].cuda_stream)
                 if timed:
                     ev[i // EV_EVERY][1].record(streams[b])
+                    if ev_g is not None:       # the frame's exchange: from the end of this rank's kernel ...
+                        ev_g[i // EV_EVERY][0].record(streams[b])
+                        gather_end[b] = ev_g[i // EV_EVERY][1]
                 if world > 1:                  # the frame's single collective, asynchronous, ordered after b's kernel
                     src = send2[b] if coll_dev == "cuda" else send2[b].cpu()
                     if rank == 0:
@@ -269,8 +349,11 @@ def main():
     def make_sync(streams):
         def sync(k):
             if world > 1:
-                finish(k & 1, streams)
-                finish((k + 1) & 1, streams)
+                for b in (k & 1, (k + 1) & 1):
+                    finish(b, streams)
+                    if gather_end[b] is not None:
+                        gather_end[b].record(streams[b])
+                        gather_end[b] = None
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
@@ -288,10 +371,40 @@ def main():
     # loop ~15 us of stream time, 3 % of a frame: sampling keeps the timed region honest)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range((args.steps + EV_EVERY - 1) // EV_EVERY)]
-    elapsed, k = timed_loop(make_step(streams, ev, lambda k, b: fds[b]), args.steps, args.warmup, make_sync(streams), world)
+    ev_g = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in ev] if world > 1 else None
+    step_main = make_step(streams, ev, lambda k, b: fds[b], ev_g)
+    sync_main = make_sync(streams)
+    # untimed pre-roll until the clock has settled under this workload (the timed region stays `steps` frames after
+    # `warmup` more); clocks read while launches are in flight, before and at the end of the timed loop
+    k0, pre = preroll(step_main, sync_main, reduce_max) if not args.no_preroll else (0, None)
+    clocks = {}
+    if rank == 0:
+        for _ in range(50):
+            step_main(k0, None)
+            k0 += 1
+        clocks["before"] = read_clocks(fast_only=not args.smi_clocks)
+        sync_main(k0)
+    elif world > 1:
+        for _ in range(50):
+            step_main(k0, None)
+            k0 += 1
+        sync_main(k0)
+    elapsed, k, c_end = timed_loop(step_main, args.steps, args.warmup, sync_main, world, k0=k0,
+                                   mid=(lambda: read_clocks(fast_only=True)) if rank == 0 else None)
+    if rank == 0:
+        clocks["end_of_timed_loop"] = c_end
     packed = packed2[(k - 1) & 1]
     rgba = rgba2[(k - 1) & 1]
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_g])) if ev_g else 0.0
+    # per-rank figures ("report per-GPU kernel times"): every rank's own launch duration and loop time
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([kernel_ms, elapsed / args.steps * 1e3, float(rows)], dtype=torch.float64, device=coll_dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"kernel_ms": [float(t[0]) for t in allr], "ms_per_step": [float(t[1]) for t in allr],
+                    "rows": [int(t[2]) for t in allr]}
     elapsed, kernel_ms = reduce_max(elapsed, kernel_ms)
     ms_per_step = elapsed / args.steps * 1e3
 
@@ -307,19 +420,25 @@ def main():
         def cam_of(k):
             return cam_at(k % 8 if (k // 8) % 2 == 0 else 7 - (k % 8))
         s1 = [main_stream, main_stream]
-        e_mv, _ = timed_loop(make_step(s1, None, lambda k, b: make_fd(b, cam_of(k))), args.steps, args.warmup, make_sync(s1), world)
+        e_mv, _, _ = timed_loop(make_step(s1, None, lambda k, b: make_fd(b, cam_of(k))), args.steps, args.warmup, make_sync(s1), world)
         # the same positions, each held for an eighth of the loop: the same pixels to render, 8 table builds in all
         hold = max(1, (args.steps + args.warmup + 7) // 8)
-        e_st, _ = timed_loop(make_step(s1, None, lambda k, b: make_fd(b, cam_at((k // hold) % 8))), args.steps, args.warmup,
-                             make_sync(s1), world)
-        e_pl, _ = timed_loop(make_step(two_streams, None, lambda k, b: fds[b]), args.steps, args.warmup, make_sync(two_streams), world)
-        # the same serial loop with the tiles started in grid order (what a launch does without durations of earlier frames)
+        e_st, _, _ = timed_loop(make_step(s1, None, lambda k, b: make_fd(b, cam_at((k // hold) % 8))), args.steps, args.warmup,
+                                make_sync(s1), world)
+        e_pl, _, _ = timed_loop(make_step(two_streams, None, lambda k, b: fds[b]), args.steps, args.warmup, make_sync(two_streams), world)
+        # the launch-order A/B under IDENTICAL conditions: the same serial loop, the same sampled HIP events, the same
+        # steps and warm-up, back to back on the settled GPU -- first with the tiles started in grid order (what a launch
+        # does without durations of earlier frames), then once more in the library's order
+        ev_ab = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in ev]
         scene.set_tile_order(0)
-        e_go, _ = timed_loop(make_step(s1, None, lambda k, b: fds[b]), args.steps, args.warmup, make_sync(s1), world)
+        e_go, _, _ = timed_loop(make_step(s1, ev_ab, lambda k, b: fds[b]), args.steps, args.warmup, make_sync(s1), world)
         scene.set_tile_order(args.tile_order)
-        e_mv, e_st, e_pl, e_go = reduce_max(e_mv, e_st, e_pl, e_go)
+        e_lo, _, _ = timed_loop(make_step(s1, ev_ab, lambda k, b: fds[b]), args.steps, args.warmup, make_sync(s1), world)
+        e_mv, e_st, e_pl, e_go, e_lo = reduce_max(e_mv, e_st, e_pl, e_go, e_lo)
         rays = w * h * args.spp
         extras["grid_order"] = {"ms_per_step": e_go / args.steps * 1e3, "Mrays_per_s": rays / (e_go / args.steps) / 1e6,
+                                "library_order_same_conditions_ms": e_lo / args.steps * 1e3,
+                                "gain_of_the_library_order": 1.0 - e_lo / e_go,
                                 "note": "rt_scene_set_tile_order(0): tiles started row-major as the grid comes. The default starts blocks "
                                         "of 16x16 tiles in the order of their longest tile (wave durations recorded by the frame kernel in "
                                         "the previous launch, sorted on the device after 1, 2, 4, 8, ... launches of an unchanged view and "
@@ -340,7 +459,7 @@ def main():
         if not args.no_cull and not args.table_lds and args.tile in (0, 8):
             exact = rgba2[(k - 1) & 1].clone()
             fds_fast = [make_fd(b, fast=True) for b in range(2)]
-            e_fa, kf = timed_loop(make_step(s1, None, lambda k, b: fds_fast[b]), args.steps, args.warmup, make_sync(s1), world)
+            e_fa, kf, _ = timed_loop(make_step(s1, None, lambda k, b: fds_fast[b]), args.steps, args.warmup, make_sync(s1), world)
             got = rgba2[(kf - 1) & 1]
             rel = (got[..., :3].double() - exact[..., :3].double()).abs() / exact[..., :3].double().abs().clamp_min(1e-3)
             worst = rel.amax(dim=2)
@@ -410,6 +529,11 @@ def main():
                        "frames_in_flight": nfl,
                        "outputs": "float4 RGBA + packed 0x00RRGGBB in HBM"},
             "kernel_ms": kernel_ms,
+            "clocks": {**clocks, "nominal_sclk_mhz": 2400,
+                       "note": "read while launches of this workload were in flight (an idle GPU reports its idle clock); "
+                               "every fraction of a peak in this line is against the NOMINAL peak (8 TB/s, 157.3 TFLOP/s, "
+                               "2.4 GHz issue), not scaled to the clock read here"},
+            "preroll": pre,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["derived"].get("hbm_traffic_bytes") if pmc else None,
                          "algorithmic_bytes_per_launch": band_bytes, "launch_ms": launch_ms,
@@ -442,6 +566,11 @@ def main():
             out["work"]["algorithmic_rate_TFLOPs"] = brute_tests * FLOP_PER_TEST / (ms_per_step * 1e-3) / 1e12
             out["work"]["executed_over_brute_force"] = slots / brute_tests
         if world > 1:
+            out["per_rank"] = per_rank
+            out["gather_ms"] = {"root_kernel_end_to_assembled_ms": gather_ms,
+                                "note": "HIP events on the root's frame stream around every 4th frame's exchange: from the end of "
+                                        "the root's own kernel to the gather having delivered every rank's rows and "
+                                        "rt_assemble_rows24 having put them in place (includes waiting for the slowest rank)"}
             # the assembled frame against a full single-GPU render of the same frame (untimed, rank 0)
             full = scene.render(w, h, spp=args.spp, cull=not args.no_cull, tile=args.tile, want_rgba=False)["packed"]
             torch.cuda.synchronize()

@@ -14,8 +14,12 @@
  * fatal convention: print, reset the device, exit(99) -- memManager.cpp:3-11).
  *
  * Threading: like the reference (single Win32 UI thread) the entry points are
- * not thread-safe; use one caller thread per process. One process drives one
- * GPU; multi-GPU runs are one process per GPU.
+ * not thread-safe; use one caller thread per process. A process drives one GPU
+ * through rt_scene_* / rt_launch_raytrace / update(), or several GPUs of the node
+ * through rt_multi_* (one process, one scene per device; update() after
+ * rt_config_set_gpus(n)); hosts that run one process per GPU (bench.py under
+ * torch.distributed) render their rows with rt_scene_render and run the gather
+ * themselves (rt_assemble_rows24 is its root side). See INTEGRATION.md.
  */
 #ifndef RT_ENGINE_H
 #define RT_ENGINE_H
@@ -260,6 +264,8 @@ int rt_config_set_seed(unsigned int seed);   /* MSVC rand() seed; default 1     
  * those uses the synthetic textures and no mesh. Call before rt_on_start().                  */
 int rt_config_set_assets(const char *object_texture, const char *sky_texture, const char *mesh_obj);
 rt_camera *rt_config_camera(void);           /* the global `cam` (kernel.cu:1695)     */
+rt_object *rt_config_object(void);           /* the global `objs` (kernel.cu:1699); NULL before onStart(). update()
+                                                reads its sphere / plane / cube / mesh fields every frame */
 rt_light *rt_config_lights(int *count);      /* the global `lights` (kernel.cu:1694)  */
 float rt_default_aspect(void);               /* (float)tan(90*0.5*3.1415/180), :1701  */
 double rt_last_frame_ms(void);               /* device time of the last rt_update()   */
@@ -370,11 +376,15 @@ void rt_graph_destroy(rt_frame_graph *g);
  * small kernel there scatters the rows home and widens them to the     *
  * 0x00RRGGBB words setPixelBuff() consumes (kernel.cu:1788). update()  *
  * takes this path when rt_config_set_gpus(n > 1) was called (or the    *
- * application's environment says RT_GPUS=n).                           *
+ * application's environment said RT_GPUS=n when onStart() ran).        *
  * ------------------------------------------------------------------ */
 typedef struct rt_multi rt_multi;
-enum { RT_MULTI_AUTO = 0,       /* RCCL for distinct devices                                         */
-       RT_MULTI_RCCL = 1,       /* ncclCommInitAll + one ncclGather per frame (librccl loaded with dlopen) */
+enum { RT_MULTI_AUTO = 0,       /* RCCL for distinct devices IF its gather passes a self-test at creation
+                                   (every rank's 256 known bytes arrive in its slot of the root's buffer),
+                                   else peer copies; rt_multi_note() says which and why              */
+       RT_MULTI_RCCL = 1,       /* ncclCommInitAll + one ncclGather per frame (librccl loaded with dlopen);
+                                   creation fails if the self-test does. With ONE device the whole exchange
+                                   still runs (24-bit rows, one-rank in-place gather, scatter kernel)  */
        RT_MULTI_PEER_COPY = 2   /* the first device pulls the rows with hipMemcpyPeerAsync (SDMA over xGMI);
                                    accepts the same device several times (one-GPU rehearsal of the path) */ };
 rt_multi *rt_multi_create(int n_gpus);                       /* devices 0 .. n_gpus-1, RT_MULTI_AUTO; NULL on failure */
@@ -391,11 +401,17 @@ int rt_multi_set_mesh(rt_multi *m, const rt_mesh *mesh);
 int rt_multi_set_texture(rt_multi *m, const float *r, const float *g, const float *b, int w, int h);
 int rt_multi_set_sky(rt_multi *m, const rt_sphere *box, const float *r, const float *g, const float *b, int w, int h);
 int rt_multi_set_lights(rt_multi *m, const rt_light *lights, int n);
-/* One frame (width, height, aspect, cam and opts.spp / cull / tile of `fd`; its output pointers and
- * row bands are ignored). The assembled frame lands in `pixels_dev0` (memory of the first device) or,
- * if that is NULL, in an internal buffer (rt_multi_frame). Asynchronous; two frames may be in flight. */
+/* One frame, or one row band of it (width, height, aspect, cam and opts.spp / cull / tile of `fd`;
+ * opts.y0 / y1 select a band of whole 16-row blocks, dealt to the devices from the band's first row;
+ * its output pointers and interleave fields are ignored). The assembled rows land at their place in
+ * `pixels_dev0` (the WHOLE frame's buffer in memory of the first device) or, if that is NULL, in an
+ * internal buffer (rt_multi_frame). Asynchronous; two frames (or bands) may be in flight. */
 int rt_multi_render(rt_multi *m, const rt_frame_desc *fd, uint32_t *pixels_dev0);
 int rt_multi_sync(rt_multi *m);                              /* wait for every frame enqueued so far */
+int rt_multi_stream_wait(rt_multi *m, void *stream);         /* `stream` (first device) waits ON THE DEVICE for the frame /
+                                                                band enqueued last: copies of it need no host wait */
+const char *rt_multi_note(const rt_multi *m);                /* transport chosen at creation, and why */
+unsigned long long rt_multi_gathers(const rt_multi *m);      /* ncclGather groups issued so far (RCCL transport) */
 const uint32_t *rt_multi_frame(const rt_multi *m);           /* device pointer of the last assembled frame */
 int rt_multi_download(rt_multi *m, uint32_t *host);          /* sync + copy the last frame to host memory */
 /* The root side of the exchange alone, for hosts that run the gather themselves (one process per GPU:

@@ -220,6 +220,10 @@ def load_library():
         "rt_multi_set_lights": (ci, [vp, C.POINTER(Light), ci]),
         "rt_multi_render": (ci, [vp, C.POINTER(FrameDesc), vp]),
         "rt_multi_sync": (ci, [vp]),
+        "rt_multi_stream_wait": (ci, [vp, vp]),
+        "rt_multi_note": (C.c_char_p, [vp]),
+        "rt_multi_gathers": (C.c_ulonglong, [vp]),
+        "rt_config_object": (C.POINTER(Object), []),
         "rt_multi_frame": (vp, [vp]),
         "rt_multi_download": (ci, [vp, vp]),
         "rt_config_set_gpus": (ci, [ci]),
@@ -426,7 +430,7 @@ class Scene:
         rows = (y1 if y1 else height) - y0
         if kw.get("interleave") is not None:
             cnt, idx, blk = kw["interleave"]
-            rows = len(interleaved_rows(height, idx, cnt, blk or 16))
+            rows = len(interleaved_rows(rows, idx, cnt, blk or 16))   # blocks are dealt from the band's first row
         packed = torch.empty((rows, width), dtype=torch.int32, device="cuda")
         rgba = torch.empty((rows, width, 4), dtype=torch.float32, device="cuda") if want_rgba else None
         stats = torch.zeros(RT_STATS_COUNT, dtype=torch.int64, device="cuda") if want_stats else None

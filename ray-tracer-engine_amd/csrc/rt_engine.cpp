@@ -1024,7 +1024,7 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, const floa
         bool owns_rows = true;
         if (o.interleave_count > 1) {
             const int b = o.interleave_rows > 0 ? o.interleave_rows : 16;
-            owns_rows = b > 0 && (long long)o.interleave_index * b < fd->height;
+            owns_rows = b > 0 && (long long)o.interleave_index * b < (y1 - y0);
         }
         if (owns_rows && !fd->pixels && !o.rgba && !o.packed24) {
             rt_set_error("rt_scene_render: no output buffer (pixels, opts.rgba and opts.packed24 are all null)");
@@ -1048,18 +1048,19 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, const floa
     fc->local_rows = y1 - y0;
     if (o.interleave_count > 1) {
         const int b = o.interleave_rows > 0 ? o.interleave_rows : 16;
-        if (o.y0 != 0 || (o.y1 != 0 && o.y1 != fd->height) || b % 16 != 0 || o.interleave_index < 0 ||
-            o.interleave_index >= o.interleave_count) {
-            rt_set_error("rt_scene_render: bad interleave (count=%d index=%d rows=%d; y0/y1 must be 0)",
-                         o.interleave_count, o.interleave_index, b);
+        // with a row band the blocks are dealt from the band's first row (which must start a block)
+        if (b % 16 != 0 || y0 % b != 0 || o.interleave_index < 0 || o.interleave_index >= o.interleave_count) {
+            rt_set_error("rt_scene_render: bad interleave (count=%d index=%d rows=%d; y0=%d must be a multiple of rows)",
+                         o.interleave_count, o.interleave_index, b, y0);
             return RT_ERR_INVALID;
         }
         fc->il_count = o.interleave_count;
         fc->il_index = o.interleave_index;
         fc->il_rows = b;
+        const int band = y1 - y0;
         int rows = 0;   // rows of the blocks this rank owns
-        for (int k = o.interleave_index; k * b < fd->height; k += o.interleave_count)
-            rows += (fd->height - k * b < b) ? fd->height - k * b : b;
+        for (int k = o.interleave_index; k * b < band; k += o.interleave_count)
+            rows += (band - k * b < b) ? band - k * b : b;
         fc->local_rows = rows;   // may be 0 (more ranks than row blocks): the launch is then skipped
     }
     fc->n_planes = s->n_planes;

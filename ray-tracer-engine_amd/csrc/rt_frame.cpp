@@ -75,7 +75,8 @@ static float aspect = 0.f;
 // rt_config_set_assets(), else the environment of the APPLICATION SHELL (RT_OBJECT_TEXTURE,
 // RT_SKY_TEXTURE, RT_MESH_OBJ, read once in onStart), else the synthetic stand-ins
 static std::string cfg_object_texture, cfg_sky_texture, cfg_mesh_obj;
-static int cfg_gpus = 0;                 // 0: not set (RT_GPUS of the application's environment, else 1)
+static int cfg_gpus = 0;                 // 0: not set (RT_GPUS of the application's environment when onStart() ran, else 1)
+static int env_gpus = 0;                 // RT_GPUS as onStart() found it (the environment is not read per frame)
 static int cfg_sphere_count = 1024;      // the reference ships 0 (kernel.cu:1231); BASELINE configs set it
 static unsigned int cfg_seed = 1;        // un-seeded MSVC rand() starts from state 1
 
@@ -116,6 +117,7 @@ extern "C" int rt_config_set_gpus(int n)
     return RT_OK;
 }
 extern "C" rt_camera *rt_config_camera(void) { return &cam; }
+extern "C" rt_object *rt_config_object(void) { return objs; }   // the global `objs` (kernel.cu:1699); null before onStart()
 extern "C" rt_light *rt_config_lights(int *count)
 {
     if (count) *count = light_size;
@@ -134,6 +136,11 @@ static std::string asset(const std::string &configured, const char *env_name, co
 void onStart()
 {
     aspect = rt_default_aspect();                                  // kernel.cu:1701
+    {   // the application shell's environment, read here once (like the asset paths), never by update()
+        const char *e = getenv("RT_GPUS");
+        env_gpus = (e && *e) ? atoi(e) : 0;
+        if (env_gpus < -64 || env_gpus > 64) env_gpus = 0;
+    }
 
     objs = (rt_object *)rt_managed_alloc(sizeof(rt_object));       // `new object()` through memManager
     if (!objs) return;
@@ -193,8 +200,8 @@ static struct MultiRes {
     rt_multi *m = nullptr;
     int gpus = 0;
     const void *tex_key = nullptr, *sky_key = nullptr, *mesh_key = nullptr;
-    std::vector<char> spheres_prev, lights_prev;
-    int planes_prev = -1, cubes_prev = -1;
+    std::vector<char> spheres_prev, lights_prev, planes_prev, cubes_prev;
+    bool planes_set = false, cubes_set = false;
 } mr;
 
 static int update_multi(int gpus, int width, int height)
@@ -236,13 +243,18 @@ static int update_multi(int gpus, int width, int height)
         if ((rc = rt_multi_set_mesh(mr.m, (objs->mesh1 && objs->mesh1->bvhbox_count > 0) ? objs->mesh1 : nullptr)) != RT_OK) return rc;
         mr.mesh_key = objs->mesh1;
     }
-    if (objs->plane_count != mr.planes_prev) {
-        if ((rc = rt_multi_set_planes(mr.m, objs->d_planes, objs->plane_count)) != RT_OK) return rc;
-        mr.planes_prev = objs->plane_count;
+    // planes and cubes by CONTENT, as the single-GPU path passes them every frame (a plane that moves must move)
+    const size_t pbytes = sizeof(rt_plane) * (size_t)(objs->plane_count > 0 && objs->d_planes ? objs->plane_count : 0);
+    if (!mr.planes_set || mr.planes_prev.size() != pbytes || (pbytes && memcmp(mr.planes_prev.data(), objs->d_planes, pbytes) != 0)) {
+        if ((rc = rt_multi_set_planes(mr.m, objs->d_planes, pbytes ? objs->plane_count : 0)) != RT_OK) return rc;
+        mr.planes_prev.assign((const char *)objs->d_planes, (const char *)objs->d_planes + pbytes);
+        mr.planes_set = true;
     }
-    if (objs->cube_count != mr.cubes_prev) {
-        if ((rc = rt_multi_set_cubes(mr.m, objs->d_cubes, objs->cube_count)) != RT_OK) return rc;
-        mr.cubes_prev = objs->cube_count;
+    const size_t cbytes = sizeof(rt_cube) * (size_t)(objs->cube_count > 0 && objs->d_cubes ? objs->cube_count : 0);
+    if (!mr.cubes_set || mr.cubes_prev.size() != cbytes || (cbytes && memcmp(mr.cubes_prev.data(), objs->d_cubes, cbytes) != 0)) {
+        if ((rc = rt_multi_set_cubes(mr.m, objs->d_cubes, cbytes ? objs->cube_count : 0)) != RT_OK) return rc;
+        mr.cubes_prev.assign((const char *)objs->d_cubes, (const char *)objs->d_cubes + cbytes);
+        mr.cubes_set = true;
     }
     rt_frame_desc fd;
     memset(&fd, 0, sizeof fd);
@@ -253,9 +265,20 @@ static int update_multi(int gpus, int width, int height)
     fd.cam = cam;
     fd.opts.struct_size = sizeof fd.opts;
     fd.opts.cull = -1;
-    if ((rc = rt_multi_render(mr.m, &fd, fr.d_pixels)) != RT_OK) return rc;
-    if ((rc = rt_multi_sync(mr.m)) != RT_OK) return rc;
-    RT_HIP(hipMemcpy(fr.h_pixels, fr.d_pixels, sizeof(uint32_t) * (size_t)width * (size_t)height, hipMemcpyDeviceToHost));
+    // Row bands, as the single-GPU path below: every device renders its blocks of band k+1 while band k is
+    // gathered, scattered home and copied to the pinned buffer (the copy stream waits for the band's assembly
+    // on the device; the host waits once, at the end).
+    const int bands = (height >= 512) ? 3 : 1;
+    for (int k = 0; k < bands; ++k) {
+        const int y0 = (int)((long long)height * k / bands) & ~15, y1 = (k + 1 == bands) ? height : ((int)((long long)height * (k + 1) / bands) & ~15);
+        fd.opts.y0 = y0;
+        fd.opts.y1 = y1;
+        if ((rc = rt_multi_render(mr.m, &fd, fr.d_pixels)) != RT_OK) return rc;
+        if ((rc = rt_multi_stream_wait(mr.m, fr.copy_stream)) != RT_OK) return rc;
+        RT_HIP(hipMemcpyAsync(fr.h_pixels + (size_t)y0 * width, fr.d_pixels + (size_t)y0 * width,
+                              (size_t)width * (size_t)(y1 - y0) * sizeof(uint32_t), hipMemcpyDeviceToHost, fr.copy_stream));
+    }
+    RT_HIP(hipStreamSynchronize(fr.copy_stream));
     return RT_OK;
 }
 
@@ -289,13 +312,10 @@ void update()
         fr.height = height;
     }
 
-    {   // several GPUs: rt_config_set_gpus(n), else RT_GPUS of the application's environment (read per frame: cheap)
-        int gpus = cfg_gpus;
-        if (gpus == 0) {
-            const char *e = getenv("RT_GPUS");
-            gpus = (e && *e) ? atoi(e) : 1;
-        }
-        if (gpus > 1 || gpus < -1) {
+    {   // several GPUs: rt_config_set_gpus(n), else what onStart() found in the application's environment.
+        // A frame whose width is no multiple of 4 has no 24-bit rows: it is rendered by the first device alone.
+        const int gpus = cfg_gpus != 0 ? cfg_gpus : (env_gpus != 0 ? env_gpus : 1);
+        if ((gpus > 1 || gpus < -1) && width % 4 == 0) {
             (void)hipSetDevice(0);
             const int rc = update_multi(gpus, width, height);
             if (rc != RT_OK) {

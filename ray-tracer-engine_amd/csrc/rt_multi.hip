@@ -19,6 +19,7 @@
 #include <dlfcn.h>
 
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/rt_engine.h"
@@ -40,6 +41,7 @@ int rows_of(int height, int rank, int n)
 // One thread per four pixels of the assembled frame: three dwords in (12 bytes = B,G,R of four
 // pixels), one uint4 out. recv holds `n` slots of `slot_rows` rows of `width * 3` bytes each;
 // frame row y lives in slot (y / 16) % n at local row (y / 16 / n) * 16 + y % 16.
+// `height` rows are assembled (a whole frame, or one row band of it whose first row `frame` points at).
 __global__ void rt_scatter_rows24(const unsigned *__restrict__ recv, uint4 *__restrict__ frame, int width, int height, int n,
                                   int slot_rows)
 {
@@ -110,6 +112,9 @@ struct rt_multi {
     int width = 0, height = 0, slot_rows = 0;
     unsigned long long frames = 0;
     uint32_t *last = nullptr;
+    int last_set = -1;                                 // buffer set of the last enqueued frame / band
+    unsigned long long gathers = 0;                    // ncclGather groups issued (rt_multi_gathers)
+    std::string note;                                  // what create() decided and why (rt_multi_note)
 };
 
 #define RT_NCCL(expr)                                                                                   \
@@ -165,6 +170,76 @@ extern "C" void rt_multi_destroy(rt_multi *m)
     delete m;
 }
 
+static int enable_peer(int root, int peer)
+{
+    if (peer == root) return RT_OK;
+    int can = 0;
+    RT_HIP(hipDeviceCanAccessPeer(&can, root, peer));
+    if (can) {
+        RT_HIP(hipSetDevice(root));
+        const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) RT_HIP(e);
+        (void)hipGetLastError();
+    }
+    return RT_OK;
+}
+
+// Load RCCL, create the communicators (one process, one per device) and run the frame's exchange once on a
+// known pattern: every device sends 256 bytes of (0x40 + rank), in place on the root exactly as
+// rt_multi_render does it, and the root's receive buffer is checked on the host. The transport is only
+// taken when that gather delivered every rank's bytes to its slot.
+static int rccl_bring_up(rt_multi *m, const int *devices)
+{
+    const int n = m->n;
+    if (!g_rccl.load()) {
+        rt_set_error("rt_multi_create: librccl.so is not loadable (%s)", dlerror());
+        return RT_ERR_UNSUPPORTED;
+    }
+    std::vector<ncclComm_t> comms((size_t)n);
+    RT_NCCL(g_rccl.CommInitAll(comms.data(), n, devices));
+    for (int i = 0; i < n; ++i) m->dev[i].comm = comms[i];
+    const size_t slot = 256;
+    std::vector<unsigned char *> bufs((size_t)n, nullptr);
+    int rc = RT_OK;
+    auto body = [&]() -> int {
+        for (int i = 0; i < n; ++i) {
+            RT_HIP(hipSetDevice(devices[i]));
+            RT_HIP(hipMalloc((void **)&bufs[(size_t)i], i == 0 ? slot * (size_t)n : slot));
+            if (i == 0) RT_HIP(hipMemsetAsync(bufs[0], 0, slot * (size_t)n, m->dev[0].stream));
+            RT_HIP(hipMemsetAsync(bufs[(size_t)i], 0x40 + i, slot, m->dev[i].stream));
+        }
+        RT_NCCL(g_rccl.GroupStart());
+        for (int i = 0; i < n; ++i) {
+            RT_HIP(hipSetDevice(devices[i]));
+            RT_NCCL(g_rccl.Gather(bufs[(size_t)i], i == 0 ? (void *)bufs[0] : nullptr, slot, ncclUint8, 0, m->dev[i].comm, m->dev[i].stream));
+        }
+        RT_NCCL(g_rccl.GroupEnd());
+        for (int i = 0; i < n; ++i) {
+            RT_HIP(hipSetDevice(devices[i]));
+            RT_HIP(hipStreamSynchronize(m->dev[i].stream));
+        }
+        std::vector<unsigned char> host(slot * (size_t)n);
+        RT_HIP(hipSetDevice(devices[0]));
+        RT_HIP(hipMemcpy(host.data(), bufs[0], host.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i)
+            for (size_t k = 0; k < slot; ++k)
+                if (host[slot * (size_t)i + k] != (unsigned char)(0x40 + i)) {
+                    rt_set_error("rt_multi_create: RCCL gather self-test: byte %zu of rank %d's slot is 0x%02x, expected 0x%02x",
+                                 k, i, host[slot * (size_t)i + k], 0x40 + i);
+                    return RT_ERR_HIP;
+                }
+        return RT_OK;
+    };
+    rc = body();
+    for (int i = 0; i < n; ++i)
+        if (bufs[(size_t)i]) {
+            (void)hipSetDevice(devices[i]);
+            (void)hipFree(bufs[(size_t)i]);
+        }
+    (void)hipSetDevice(devices[0]);
+    return rc;
+}
+
 static int create_impl(rt_multi *m, const int *devices, int n, int transport)
 {
     int have = 0;
@@ -177,7 +252,8 @@ static int create_impl(rt_multi *m, const int *devices, int n, int transport)
         }
         for (int j = 0; j < i; ++j) distinct = distinct && devices[i] != devices[j];
     }
-    if (transport == RT_MULTI_AUTO) transport = distinct ? RT_MULTI_RCCL : RT_MULTI_PEER_COPY;
+    const bool automatic = transport == RT_MULTI_AUTO;
+    if (automatic) transport = distinct ? RT_MULTI_RCCL : RT_MULTI_PEER_COPY;
     if (transport == RT_MULTI_RCCL && !distinct) {
         rt_set_error("rt_multi_create: the RCCL transport needs distinct devices (use RT_MULTI_PEER_COPY)");
         return RT_ERR_INVALID;
@@ -192,15 +268,9 @@ static int create_impl(rt_multi *m, const int *devices, int n, int transport)
         d.scene = rt_scene_create();
         RT_HIP(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
         for (hipEvent_t &e : d.rendered) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        if (transport == RT_MULTI_PEER_COPY && d.device != devices[0]) {
-            int can = 0;
-            RT_HIP(hipDeviceCanAccessPeer(&can, devices[0], d.device));
-            if (can) {
-                RT_HIP(hipSetDevice(devices[0]));
-                const hipError_t e = hipDeviceEnablePeerAccess(d.device, 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) RT_HIP(e);
-                (void)hipGetLastError();
-            }
+        if (transport == RT_MULTI_PEER_COPY) {
+            const int prc = enable_peer(devices[0], d.device);
+            if (prc != RT_OK) return prc;
         }
     }
     RT_HIP(hipSetDevice(devices[0]));
@@ -210,13 +280,27 @@ static int create_impl(rt_multi *m, const int *devices, int n, int transport)
         RT_HIP(hipEventCreateWithFlags(&m->pulled[b], hipEventDisableTiming));
     }
     if (transport == RT_MULTI_RCCL) {
-        if (!g_rccl.load()) {
-            rt_set_error("rt_multi_create: librccl.so is not loadable (%s)", dlerror());
-            return RT_ERR_UNSUPPORTED;
+        const int rc = rccl_bring_up(m, devices);
+        if (rc != RT_OK) {
+            if (!automatic) return rc;
+            // RT_MULTI_AUTO: the collective library is missing or its gather did not deliver -- the peer-copy
+            // transport moves the same rows over the same links
+            m->note = std::string("RCCL transport unusable (") + rt_last_error() + "); using peer copies";
+            for (Dev &d : m->dev) {
+                if (d.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(d.comm);
+                d.comm = nullptr;
+            }
+            m->transport = RT_MULTI_PEER_COPY;
+            for (int i = 1; i < n; ++i) {
+                const int prc = enable_peer(devices[0], devices[i]);
+                if (prc != RT_OK) return prc;
+            }
+            RT_HIP(hipSetDevice(devices[0]));
+        } else {
+            m->note = "RCCL transport: gather self-test passed";
         }
-        std::vector<ncclComm_t> comms((size_t)n);
-        RT_NCCL(g_rccl.CommInitAll(comms.data(), n, devices));   // one process, one communicator per device
-        for (int i = 0; i < n; ++i) m->dev[i].comm = comms[i];
+    } else {
+        m->note = "peer-copy transport";
     }
     return RT_OK;
 }
@@ -309,10 +393,12 @@ static int ensure_buffers(rt_multi *m, int width, int height)
     return RT_OK;
 }
 
-// One frame. fd: the whole frame (width, height, aspect, cam; opts.spp / cull / tile honoured; row
-// bands, interleave and output pointers of fd are ignored). The assembled 0x00RRGGBB frame lands in
-// `pixels_dev0` (device memory of the first device) or, when that is null, in an internal buffer
-// (rt_multi_frame). Asynchronous: returns when the work is enqueued; two frames may be in flight.
+// One frame, or one row band of it. fd: the whole frame's width, height, aspect, cam; opts.spp / cull / tile
+// honoured; opts.y0 / y1 (both multiples of 16 rows, or 0 / 0 for the whole frame) select a row band, whose
+// 16-row blocks are dealt to the devices from the band's first row; interleave and output pointers of fd are
+// ignored. The assembled 0x00RRGGBB rows land at their place in `pixels_dev0` (device memory of the first
+// device, the WHOLE frame's buffer) or, when that is null, in an internal frame buffer (rt_multi_frame).
+// Asynchronous: returns when the work is enqueued; two frames (or bands) may be in flight.
 extern "C" int rt_multi_render(rt_multi *m, const rt_frame_desc *fd, uint32_t *pixels_dev0)
 {
     if (!m || !fd || fd->width <= 0 || fd->height <= 0) {
@@ -320,22 +406,38 @@ extern "C" int rt_multi_render(rt_multi *m, const rt_frame_desc *fd, uint32_t *p
         return RT_ERR_INVALID;
     }
     const int w = fd->width, h = fd->height, n = m->n;
+    int y0 = fd->opts.y0, y1 = fd->opts.y1;
+    if (y0 == 0 && y1 == 0) y1 = h;
+    if (y0 < 0 || y1 > h || y0 >= y1 || y0 % RT_MULTI_BLOCK != 0 || (y1 % RT_MULTI_BLOCK != 0 && y1 != h)) {
+        rt_set_error("rt_multi_render: bad row band [%d,%d) of %d rows (whole %d-row blocks)", y0, y1, h, RT_MULTI_BLOCK);
+        return RT_ERR_INVALID;
+    }
+    const int hb = y1 - y0;   // rows of this band
     int rc;
-    if (n == 1) {   // nothing to gather: the device renders the frame where it is wanted
+    // one device and no collective asked for: it renders the rows where they are wanted. (With the RCCL transport
+    // named explicitly a single device still runs the whole exchange -- 24-bit rows, the in-place one-rank
+    // gather, the scatter kernel -- so that every call of the multi-device path executes on a one-GPU box.)
+    if (n == 1 && (m->transport != RT_MULTI_RCCL || w % 4 != 0)) {
         rc = ensure_buffers(m, w, h);
         if (rc != RT_OK) return rc;
         const int b = (int)(m->frames & 1);
         RT_HIP(hipSetDevice(m->dev[0].device));
+        if (m->set_used[b]) RT_HIP(hipStreamWaitEvent(m->dev[0].stream, m->assembled[b], 0));
         rt_frame_desc f = *fd;
-        f.opts.y0 = f.opts.y1 = 0;
+        f.opts.y0 = y0;
+        f.opts.y1 = y1;
         f.opts.interleave_count = f.opts.interleave_index = f.opts.interleave_rows = 0;
         f.opts.rgba = nullptr;
         f.opts.packed24 = nullptr;
         f.opts.stats = nullptr;
-        f.pixels = pixels_dev0 ? pixels_dev0 : m->frame[b];
+        uint32_t *out = pixels_dev0 ? pixels_dev0 : m->frame[b];
+        f.pixels = out + (size_t)y0 * (size_t)w;
         rc = rt_scene_render(m->dev[0].scene, &f, m->dev[0].stream);
         if (rc != RT_OK) return rc;
-        m->last = f.pixels;
+        RT_HIP(hipEventRecord(m->assembled[b], m->dev[0].stream));
+        m->set_used[b] = true;
+        m->last = out;
+        m->last_set = b;
         m->frames++;
         return RT_OK;
     }
@@ -346,7 +448,10 @@ extern "C" int rt_multi_render(rt_multi *m, const rt_frame_desc *fd, uint32_t *p
     rc = ensure_buffers(m, w, h);
     if (rc != RT_OK) return rc;
     const int b = (int)(m->frames & 1);   // buffer set of this frame
-    const size_t slot_bytes = (size_t)m->slot_rows * (size_t)w * 3;
+    // slots of the receive buffer: the largest share of THIS band, whole blocks (a whole frame: m->slot_rows)
+    const int blocks = (hb + RT_MULTI_BLOCK - 1) / RT_MULTI_BLOCK;
+    const int slot_rows = ((blocks + n - 1) / n) * RT_MULTI_BLOCK;
+    const size_t slot_bytes = (size_t)slot_rows * (size_t)w * 3;
     Dev &root = m->dev[0];
     // every device renders its rows (3 bytes per pixel) -- the root straight into its slot of the receive buffer
     for (int d = 0; d < n; ++d) {
@@ -358,12 +463,14 @@ extern "C" int rt_multi_render(rt_multi *m, const rt_frame_desc *fd, uint32_t *p
         f.pixels = nullptr;
         f.opts.rgba = nullptr;
         f.opts.stats = nullptr;
-        f.opts.y0 = f.opts.y1 = 0;
+        f.opts.y0 = y0;
+        f.opts.y1 = y1;
         f.opts.interleave_count = n;
         f.opts.interleave_index = d;
         f.opts.interleave_rows = RT_MULTI_BLOCK;
         f.opts.packed24 = d == 0 ? (void *)m->recv[b] : (void *)dv.send[b];
-        if (rows_of(h, d, n) > 0) {
+        if (n == 1) f.opts.interleave_count = f.opts.interleave_index = f.opts.interleave_rows = 0;   // (a band as it is)
+        if (rows_of(hb, d, n) > 0) {
             rc = rt_scene_render(dv.scene, &f, dv.stream);
             if (rc != RT_OK) return rc;
         }
@@ -381,13 +488,14 @@ extern "C" int rt_multi_render(rt_multi *m, const rt_frame_desc *fd, uint32_t *p
             RT_NCCL(g_rccl.Gather(src, d == 0 ? (void *)m->recv[b] : nullptr, slot_bytes, ncclUint8, 0, dv.comm, dv.stream));
         }
         RT_NCCL(g_rccl.GroupEnd());
+        m->gathers++;
     } else {
         // the root pulls: one asynchronous peer copy per peer, all on the set's copy stream (SDMA engines)
         RT_HIP(hipSetDevice(root.device));
         assemble_on = m->copy_stream[b];
         for (int d = 0; d < n; ++d) RT_HIP(hipStreamWaitEvent(assemble_on, m->dev[d].rendered[b], 0));
         for (int d = 1; d < n; ++d) {
-            const size_t bytes = (size_t)rows_of(h, d, n) * (size_t)w * 3;
+            const size_t bytes = (size_t)rows_of(hb, d, n) * (size_t)w * 3;
             if (!bytes) continue;
             char *dst = (char *)m->recv[b] + slot_bytes * (size_t)d;
             if (m->dev[d].device == root.device)   // the same device twice (one-GPU rehearsal of the path)
@@ -399,16 +507,33 @@ extern "C" int rt_multi_render(rt_multi *m, const rt_frame_desc *fd, uint32_t *p
     // rows home, 24 -> 32 bits
     RT_HIP(hipSetDevice(root.device));
     uint32_t *out = pixels_dev0 ? pixels_dev0 : m->frame[b];
-    const long long threads = (long long)(w / 4) * h;
+    const long long threads = (long long)(w / 4) * hb;
     hipLaunchKernelGGL(rt_scatter_rows24, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, assemble_on, m->recv[b],
-                       reinterpret_cast<uint4 *>(out), w, h, n, m->slot_rows);
+                       reinterpret_cast<uint4 *>(out + (size_t)y0 * (size_t)w), w, hb, n, slot_rows);
     RT_HIP(hipGetLastError());
     RT_HIP(hipEventRecord(m->assembled[b], assemble_on));
     m->set_used[b] = true;
     m->last = out;
+    m->last_set = b;
     m->frames++;
     return RT_OK;
 }
+
+// Make `stream` (a stream of the first device) wait, on the device, for the frame / band enqueued last:
+// what follows on it -- a copy of the assembled rows to the host, a present -- then needs no host wait.
+extern "C" int rt_multi_stream_wait(rt_multi *m, void *stream)
+{
+    if (!m || m->last_set < 0) {
+        rt_set_error("rt_multi_stream_wait: nothing has been rendered");
+        return RT_ERR_INVALID;
+    }
+    RT_HIP(hipSetDevice(m->dev[0].device));
+    RT_HIP(hipStreamWaitEvent((hipStream_t)stream, m->assembled[m->last_set], 0));
+    return RT_OK;
+}
+
+extern "C" const char *rt_multi_note(const rt_multi *m) { return m ? m->note.c_str() : ""; }
+extern "C" unsigned long long rt_multi_gathers(const rt_multi *m) { return m ? m->gathers : 0ull; }
 
 // The root side of the gather as one call, for hosts that run the exchange themselves (one process
 // per GPU under torch.distributed / MPI: bench.py): `recv` holds n slots of slot_rows rows of

@@ -40,22 +40,33 @@ RT_WEAK void setPixelBuff(unsigned int *pixels)
     if (frame() && pixels) std::copy_n(pixels, frame_words(), frame());
 }
 
-// The rest of window.h:7-16 is never called by the hot path. It is defined for link parity
-// only (an application that includes window.h resolves every symbol), as plain operations
-// on the offscreen frame -- not as restatements of the Win32 helpers.
+// The rest of window.h:7-16 is never called by the hot path. It is defined so that an
+// application which includes window.h resolves every symbol and OBSERVES what the reference's
+// helpers do (window.cpp:95-129): the background pattern word(x, y) = y*x/(x+1) in int
+// arithmetic, a clear to one colour, a clamped single-pixel store, and getBuffSize() returning
+// the size of the buffer POINTER member (sizeof(render.buffmemory), 8 on x64 -- not the frame's
+// byte count).
 RT_WEAK int make_inbound(int min, int max, int val) { return std::min(std::max(val, min), max); }
 RT_WEAK void Clear_Screen(unsigned int color)
 {
     if (frame()) std::fill_n(frame(), frame_words(), color);
 }
-RT_WEAK void Set_Background() { Clear_Screen(0u); }
+RT_WEAK void Set_Background()
+{
+    if (!frame()) return;
+    const size_t w = (size_t)render.width;
+    for (size_t i = 0, n = frame_words(); i < n; ++i) {
+        const int x = (int)(i % w), y = (int)(i / w);
+        frame()[i] = (unsigned int)(y * x / (x + 1));
+    }
+}
 RT_WEAK void drawPixel(int x, int y, int color)
 {
     if (!frame() || render.width <= 0 || render.height <= 0) return;
     const int cx = make_inbound(0, render.width - 1, x), cy = make_inbound(0, render.height - 1, y);
     frame()[(size_t)cy * (size_t)render.width + (size_t)cx] = (unsigned int)color;
 }
-RT_WEAK int getBuffSize() { return (int)(frame_words() * sizeof(unsigned int)); }   // bytes of the offscreen frame
+RT_WEAK int getBuffSize() { return (int)sizeof render.buffmemory; }   // window.cpp:118-120: the pointer's size
 RT_WEAK void setScreen(int *) {}
 
 // ---- control surface of the offscreen window (C ABI) ----

@@ -98,3 +98,35 @@ def test_no_cpu_fallback(rt):
         s.set_spheres(rt.generate_spheres(8), 8)       # needs device memory
     with pytest.raises(rt.RtError):
         s.render(64, 64)
+
+
+def test_window_helpers_behave_as_the_reference_window(rt):
+    """window.h:7-16 beyond the three functions the frame driver calls: what an application that
+    links the offscreen window observes is what window.cpp:95-129 does -- Set_Background writes
+    word(x, y) = y*x/(x+1) in int arithmetic, Clear_Screen one colour, drawPixel a clamped store,
+    getBuffSize the size of the buffer POINTER member (sizeof(render.buffmemory))."""
+    import numpy as np
+    lib = rt.load_library()
+    w, h = 37, 11
+    assert lib.rt_offscreen_resize(w, h) == 0
+    px = lambda: np.ctypeslib.as_array(lib.rt_offscreen_pixels(), shape=(h, w)).copy()
+    getattr(lib, "_Z14Set_Backgroundv")()
+    yy, xx = np.mgrid[0:h, 0:w]
+    assert np.array_equal(px(), (yy * xx // (xx + 1)).astype(np.uint32))
+    clear = getattr(lib, "_Z12Clear_Screenj")
+    clear.argtypes = [C.c_uint]
+    clear(0x00123456)
+    assert (px() == 0x00123456).all()
+    draw = getattr(lib, "_Z9drawPixeliii")
+    draw.argtypes = [C.c_int, C.c_int, C.c_int]
+    draw(5, 3, 0xABCDEF)
+    draw(-7, 400, 0x010203)                       # clamped to (0, h-1)
+    got = px()
+    assert got[3, 5] == 0xABCDEF and got[h - 1, 0] == 0x010203 and (got != 0x00123456).sum() == 2
+    size = getattr(lib, "_Z11getBuffSizev")
+    size.restype = C.c_int
+    assert size() == C.sizeof(C.c_void_p)
+    inb = getattr(lib, "_Z12make_inboundiii")
+    inb.restype = C.c_int
+    inb.argtypes = [C.c_int] * 3
+    assert (inb(0, 9, -3), inb(0, 9, 4), inb(0, 9, 12)) == (0, 4, 9)

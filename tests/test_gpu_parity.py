@@ -416,6 +416,20 @@ def test_product_library_reads_no_environment(rt, gpu, monkeypatch):
     scene = Inputs(rt, 256).scene()
     rgba, packed, _ = _render(scene, 160, 90)
     assert np.array_equal(packed, g["packed"]) and np.array_equal(_bits(rgba[..., :3]), _bits(g["rgb"]))
+    # update() reads no environment either: RT_GPUS belongs to the application shell and is looked at ONCE, by
+    # onStart(). Five devices do not exist here -- a frame that obeyed the variable would end in rt_check().
+    lib = rt.load_library()
+    assert lib.rt_config_set_sphere_count(256) == 0 and lib.rt_config_set_seed(1) == 0 and lib.rt_config_set_gpus(0) == 0
+    monkeypatch.delenv("RT_GPUS", raising=False)
+    lib.rt_on_start()
+    os.environ["RT_GPUS"] = "5"
+    try:
+        assert lib.rt_offscreen_resize(160, 90) == 0
+        lib.rt_update()
+        got = np.ctypeslib.as_array(lib.rt_offscreen_pixels(), shape=(90, 160)).copy()
+        assert np.array_equal(got, g["packed"])
+    finally:
+        del os.environ["RT_GPUS"]
 
 
 # ---------------------------------------------------------------- the reference's own surfaces
@@ -714,14 +728,16 @@ def _multi_scene(rt, lib, m, inp):
     assert lib.rt_multi_set_lights(m, inp.lights, 3) == 0
 
 
-@pytest.mark.parametrize("shares,w,h,n", [(1, 160, 90, 256), (2, 160, 90, 1024), (3, 164, 100, 256), (8, 160, 90, 1024),
-                                          (8, 1920, 1080, 256)])
+@pytest.mark.parametrize("shares,w,h,n", [(1, 160, 90, 256), (1, 1920, 1080, 256), (2, 160, 90, 1024), (3, 164, 100, 256),
+                                          (8, 160, 90, 1024), (8, 1920, 1080, 256), (8, 7680, 4320, 4096)])
 def test_multi_device_frame_from_the_c_abi(rt, gpu, shares, w, h, n):
     """rt_multi_*: the frame split into 16-row blocks dealt round-robin, every share rendered as
     24-bit rows, gathered to the first device and scattered home by rt_scatter_rows24 -- equal to
     the single-GPU frame bit for bit. One GPU here, so `shares` > 1 uses the same device several
-    times with the peer-copy transport (everything but the RCCL call itself runs); one share goes
-    through RT_MULTI_RCCL: librccl is loaded with dlopen and ncclCommInitAll runs."""
+    times with the peer-copy transport (everything but the RCCL call itself runs) -- up to C5's own
+    size, 7680x4320 / 4096 spheres in 8 shares; one share goes through RT_MULTI_RCCL, which runs
+    the WHOLE exchange for its single rank: dlopen, ncclCommInitAll, the gather self-test of
+    rt_multi_create, and per frame the 24-bit rows, the in-place ncclGather and the scatter kernel."""
     import torch
     lib = rt.load_library()
     inp = Inputs(rt, n)
@@ -731,6 +747,8 @@ def test_multi_device_frame_from_the_c_abi(rt, gpu, shares, w, h, n):
     transport = 1 if shares == 1 else 2
     assert lib.rt_multi_create_ex(devs, shares, transport, C.byref(m)) == 0, lib.rt_last_error()
     assert lib.rt_multi_device_count(m) == shares and lib.rt_multi_transport(m) == transport
+    note = lib.rt_multi_note(m).decode()
+    assert ("self-test passed" in note) if transport == 1 else ("peer-copy" in note), note
     _multi_scene(rt, lib, m, inp)
     sc = rt.Scene()
     fd = sc.frame_desc(w, h)
@@ -751,7 +769,25 @@ def test_multi_device_frame_from_the_c_abi(rt, gpu, shares, w, h, n):
     assert lib.rt_multi_render(m, C.byref(fd), None) == 0
     assert lib.rt_multi_download(m, host.ctypes.data) == 0
     assert np.array_equal(host, want.cpu().numpy().view(np.uint32))
+    assert lib.rt_multi_gathers(m) == (6 if transport == 1 else 0)       # one ncclGather group per frame
+    # the same frame in three row bands (what update() does to overlap the copy to the host with the next band)
+    out.zero_()
+    bands = [(0, (h // 3) & ~15), ((h // 3) & ~15, (2 * h // 3) & ~15), ((2 * h // 3) & ~15, h)]
+    for (y0, y1) in bands:
+        if y1 > y0:
+            fd.opts.y0, fd.opts.y1 = y0, y1
+            assert lib.rt_multi_render(m, C.byref(fd), out.data_ptr()) == 0, lib.rt_last_error()
+    assert lib.rt_multi_sync(m) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    fd.opts.y0, fd.opts.y1 = 8, 24                                       # not whole blocks: refused
+    assert lib.rt_multi_render(m, C.byref(fd), out.data_ptr()) != 0
     lib.rt_multi_destroy(m)
+    if n == 4096:   # C5: a band of the assembled frame against the reference's loops as written
+        sc5 = inp.scene()
+        rb = sc5.render(w, h, y0=2144, y1=2176, cull=False, want_rgba=False)["packed"]
+        torch.cuda.synchronize()
+        assert torch.equal(rb, want[2144:2176])
 
 
 def test_update_on_several_shares(rt, gpu):
@@ -764,12 +800,44 @@ def test_update_on_several_shares(rt, gpu):
     try:
         lib.rt_on_start()
         inp = Inputs(rt, 256)
-        for (w, h) in ((160, 90), (96, 54)):
+        for (w, h) in ((160, 90), (96, 54), (162, 90)):   # 162: no 24-bit rows -> that frame on the first device alone
             assert lib.rt_offscreen_resize(w, h) == 0
             lib.rt_update()
             got = np.ctypeslib.as_array(lib.rt_offscreen_pixels(), shape=(h, w)).copy()
             _, want, _ = inp.oracle_render(oracle_py, w, h)
             assert np.array_equal(got, want), (w, h)
+        # tall enough for update()'s three row bands (each gathered, scattered and copied while the next renders),
+        # camera moved between frames; against the single-GPU render of the same frames
+        import torch
+        w, h = 1920, 1080
+        assert lib.rt_offscreen_resize(w, h) == 0
+        cam = lib.rt_config_camera()
+        sc = inp.scene()
+        for z in (10.0, 10.3, 10.0):
+            cam.contents.Org.z = z
+            lib.rt_update()
+            got = np.ctypeslib.as_array(lib.rt_offscreen_pixels(), shape=(h, w)).copy()
+            c = rt.default_camera()
+            c.Org.z = z
+            want = sc.render(w, h, want_rgba=False, cam=c)["packed"]
+            torch.cuda.synchronize()
+            assert np.array_equal(got, want.cpu().numpy().view(np.uint32)), z
+        # a plane that MOVES between two frames moves on every share (contents are compared, not counts)
+        w, h = 160, 96
+        assert lib.rt_offscreen_resize(w, h) == 0
+        obj = lib.rt_config_object()
+        pl = C.cast(lib.rt_managed_alloc(40), C.POINTER(rt.Plane))
+        lib.rt_plane_init(pl, 0.0, -4.0, 0.0, 0.0, 1.0, 0.0)
+        obj.contents.d_planes, obj.contents.plane_count = pl, 1
+        lib.rt_update()
+        first = np.ctypeslib.as_array(lib.rt_offscreen_pixels(), shape=(h, w)).copy()
+        lib.rt_plane_init(pl, 0.0, -1.0, 0.0, 0.0, 1.0, 0.0)
+        lib.rt_update()
+        moved = np.ctypeslib.as_array(lib.rt_offscreen_pixels(), shape=(h, w)).copy()
+        _, want, _ = oracle_py.render(inp.spheres, inp.n, inp.tex, inp.sky, inp.sky_box, inp.lights, 3, inp.cam, w, h, inp.aspect,
+                                      nthreads=8, planes=pl, n_planes=1)
+        assert np.array_equal(moved, want) and not np.array_equal(moved, first)
+        obj.contents.d_planes, obj.contents.plane_count = None, 0
     finally:
         lib.rt_config_set_gpus(0)
 
@@ -844,3 +912,20 @@ def test_tile_order_changes_the_schedule_not_the_pixels(rt, gpu):
         torch.cuda.synchronize()
         assert torch.equal(a["packed"], b["packed"]), (k, kw)
         assert torch.equal(a["rgba"].view(torch.int32), b["rgba"].view(torch.int32)), (k, kw)
+    # No host synchronisation between launches: frames of both streams and several layouts in flight while orders are
+    # sorted and slots of the layout cache are recycled (the sort waits on the device for every frame launched so far,
+    # later launches on the other stream wait for its event). Every launch has its own output buffers; all of them are
+    # compared with the grid-order frames after ONE final synchronize.
+    torch.cuda.synchronize()
+    outs = []
+    for k in range(60):
+        cam = cams[(k * 7) % len(cams)] if k % 10 >= 6 else cams[0]          # mostly resting, moving now and then
+        kw = layouts[(k // 2) % len(layouts)] if k >= 30 else layouts[k % 3]   # three layouts, then all six (evictions)
+        st = streams[k & 1]
+        with torch.cuda.stream(st):
+            outs.append((k, kw, cam, scene.render(w, h, cam=cam, stream=st, want_rgba=False, **kw)))
+    torch.cuda.synchronize()
+    for k, kw, cam, a in outs:
+        b = plain.render(w, h, cam=cam, want_rgba=False, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(a["packed"], b["packed"]), (k, kw)
