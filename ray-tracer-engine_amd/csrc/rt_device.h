@@ -9,6 +9,40 @@
 #include <stdint.h>
 
 #define RT_DEV_MAX_LIGHTS 8
+
+// Paddings of the conservative culling tests (rt_trace.inc: beam_keeps, beam_member_test, beam_keeps_block,
+// beam_keeps_column; rt_tables.hip: cone_entry). What they must cover is the rounding of the EXACT test. intersect()
+// (kernel.cu:332-336, `quadratic()` in rt_trace.inc) can only return true if its binary32 discriminant is >= 0. With
+// eps = 2^-24, d = |o - c| and |D| = 1 (to 2e-7): the dot product h carries at most 4 eps d (three products, two sums, the
+// rounded o - c), B*B at most 20 eps d^2, 4A*C at most 40 eps d^2 (C: 6 eps d^2; 4A: 4 eps relative on |C| <= d^2 ... with
+// R <= d, else read d as R), the final subtraction 4 eps d^2: |disc_float - disc| <= 64 eps d^2 = 3.8e-6 d^2, i.e. 9.5e-7 d^2
+// in units of (distance of the ray's line from the centre)^2, 1.2e-6 d^2 with |D|^2 - 1. So the float test can return true only
+// for a line within sqrt(R^2 + 1.2e-6 d^2) of the centre. A beam's rays start within r0 <= RT_R0_CAP = 1 of the point a the
+// tests measure v = c - a from: d^2 <= 2 (|v|^2 + r0^2), needed <= 2.4e-6 |v|^2 + 2.4e-6; the tests use REL |v|^2 + ABS =
+// 4e-6 |v|^2 + 1e-5 (the surplus, 1.6e-6 |v|^2, also covers the cancellation error 3 eps |v|^2 of the tests' own
+// |v|^2 - (v.u)^2). Round 2 used 4e-5 |v|^2 + 1e-3, fifty times the noise: a third of the BASELINE spheres have R < 0.1 and
+// were tested as if R were 0.07 more.
+// Block-level tests must cover their members' paddings: sqrt(REL (|v|^2 + r0^2) + ABS) <= sqrt(REL) (|v| + r0) + sqrt(ABS)
+// <= 2e-3 |v| + 5.2e-3 for r0 <= 1, |v| <= dist + r_block.
+#ifndef RT_PAD_REL
+#define RT_PAD_REL 4.0e-6f
+#define RT_PAD_ABS 1.0e-5f
+#define RT_BLK_PAD_REL 2.1e-3f
+#define RT_BLK_PAD_ABS 0.006f
+#endif
+#define RT_R0_CAP 1.0f           // a group whose ray origins do not fit a ball of this radius is not culled for
+// Allowance on the bound of a light's sample directions (sine of the deviation from the light's axis), for what separates
+// the bound's inputs from the exact chain of kernel.cu:1438-1468: toL from a reciprocal square root against the chain's
+// re-normalised toL (|dt| <= 5e-7, which the matrix amplifies by K = 4/q + 3 <= 403 for q >= 0.01: 3e-4 of S >= 1),
+// cosf/sinf(acosf(z)) against z and sqrt(1 - z^2), the products' roundings, |v_j| <= 1 + 2e-7, the rounding of l.pos - r and
+// of the final normalise (2e-7 rad), and this bound's own binary32 evaluation (1e-5): together below 5e-4 relative.
+#ifndef RT_SPREAD_MUL
+#define RT_SPREAD_MUL 1.002f
+#define RT_SPREAD_ADD 5.0e-5f
+#endif
+#ifndef RT_ORIGIN_ADD
+#define RT_ORIGIN_ADD 1.0e-5f    // allowance on the radius of the ball around a group's ray origins (its float evaluation: 1e-6 relative)
+#endif
 #define RT_DEV_MAX_SPP 16
 #define RT_SHADOW_SAMPLES 10   // kernel.cu:1442 `for (int j = 0; j < 10; j++)`
 #ifndef RT_LIST_CAP
@@ -52,6 +86,9 @@ struct RtLightDev {
     float ux, uy, uz;   // pos / |pos| (beam axis for conservative shadow culling)
     float pos_len;      // |pos|
     float fin;          // 1 if r, g and b are all finite, else 0
+    float e1x, e1y, e1z;   // e1, e2: an orthonormal pair across u (the plane a sample direction's deviation is measured in)
+    float e2x, e2y, e2z;
+    float pad0_, pad1_;
 };
 
 struct RtPlaneDev {     // plane: a point and the normal as given (kernel.cu:364-367)

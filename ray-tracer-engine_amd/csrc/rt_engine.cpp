@@ -942,6 +942,21 @@ static void rt_build_frame_aux(const rt_scene *s, RtFrameAux *ax)
         d.ux = len > 0 ? l.pos.x / len : NAN;
         d.uy = len > 0 ? l.pos.y / len : NAN;
         d.uz = len > 0 ? l.pos.z / len : NAN;
+        // e1 = the coordinate axis least aligned with u, made orthogonal to it; e2 = u x e1 (binary64, rounded once)
+        {
+            const double u[3] = {d.ux, d.uy, d.uz};
+            const int k = (std::fabs(u[0]) <= std::fabs(u[1]) && std::fabs(u[0]) <= std::fabs(u[2])) ? 0 : (std::fabs(u[1]) <= std::fabs(u[2]) ? 1 : 2);
+            double t[3] = {0, 0, 0};
+            t[k] = 1;
+            const double dt = u[k];
+            double e1[3] = {t[0] - dt * u[0], t[1] - dt * u[1], t[2] - dt * u[2]};
+            const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+            for (double &v : e1) v /= l1;   // NaN for a light at the origin: culling is off for it anyway
+            const double e2[3] = {u[1] * e1[2] - u[2] * e1[1], u[2] * e1[0] - u[0] * e1[2], u[0] * e1[1] - u[1] * e1[0]};
+            d.e1x = (float)e1[0]; d.e1y = (float)e1[1]; d.e1z = (float)e1[2];
+            d.e2x = (float)e2[0]; d.e2y = (float)e2[1]; d.e2z = (float)e2[2];
+            d.pad0_ = d.pad1_ = 0.f;
+        }
     }
     {
         const int n_pad = (s->n_spheres + 63) & ~63;

@@ -83,7 +83,7 @@ RT_HDI ConeEnt cone_entry(float4 sph, const float org[3])
     e.ext = 0;
     e.dir[0] = e.dir[1] = e.dir[2] = 0;
     if (e.bounded) {
-        const double rc = sqrt((w > 0 ? w : 0.0) + 4.0e-5 * vv + 1.0e-3) * 1.0001;
+        const double rc = sqrt((w > 0 ? w : 0.0) + (double)RT_PAD_REL * 1.0001 * vv + (double)RT_PAD_ABS * 1.0001) * 1.0001;
         const double q = (rc * (1.0 + kcap) + r0) * 1.00025 * 1.001 / dist;
         if (!(q < 0.99)) e.bounded = false;   // the origin is inside or next to the (padded) sphere
         else e.ext = asin(q);

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 export RT_ENGINE_LIB=$PWD/ray-tracer-engine_amd/csrc/librt_engine_tuning.so
 for a in ${*:-0 16 24 7 3 1 2 4 4096}; do
   rm -rf /tmp/ab_$a
-  RT_ABLATE=$a rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d /tmp/ab_$a -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
+  RT_ABLATE=$a rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d /tmp/ab_$a -- python3 bench.py --steps 3 --warmup 1 --no-preroll --no-cpu-baseline --no-extras > /dev/null 2>&1
   ms=$(RT_ABLATE=$a python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(round(d['kernel_ms'],4))")
   python3 - $a $ms <<'PY'
 import csv,glob,sys,collections
