@@ -174,18 +174,38 @@ def read_clocks(fast_only=False):
     out = {"sclk_mhz": None, "mclk_mhz": None, "source": None}
     try:
         idx = torch.cuda.current_device()
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
-        # the idx-th card that has a DPM table (render nodes without one are not GPUs of this kind)
-        if idx < len(cards):
-            base = os.path.dirname(cards[idx])
-            for key, name in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
+        base = None
+        # the device's own PCI function (a box shows every GPU of its host under /sys, whichever one is visible to HIP)
+        pr = torch.cuda.get_device_properties(idx)
+        if all(hasattr(pr, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+            cand = "/sys/bus/pci/devices/%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            if os.path.exists(os.path.join(cand, "pp_dpm_sclk")):
+                base = cand
+                out["pci"] = os.path.basename(cand)
+        if base is None:
+            cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"),
+                           key=lambda p: int(re.search(r"card(\d+)", p).group(1)))
+            if idx < len(cards):       # the idx-th card that has a DPM table: right only when every GPU is visible
+                base = os.path.dirname(cards[idx])
+                out["pci"] = "unknown (card order)"
+        if base is not None:
+
+            def current(name):
                 with open(os.path.join(base, name)) as f:
                     for line in f:
                         m = re.search(r"(\d+)\s*[Mm][Hh]z\s*\*", line)
                         if m:
-                            out[key] = int(m.group(1))
-            if out["sclk_mhz"] is not None:
-                out["source"] = "sysfs pp_dpm_sclk/pp_dpm_mclk (level marked current)"
+                            return int(m.group(1))
+                return None
+            # the file reports one instantaneous reading of the power controller, and single readings scatter (a
+            # loaded GPU was seen to answer 170, 1518 and 2409 MHz within one run): take several, report them all
+            reads = [current("pp_dpm_sclk") for _ in range(3 if fast_only else 9)]
+            reads = [r for r in reads if r is not None]
+            if reads:
+                out["sclk_mhz"] = max(reads)
+                out["sclk_reads_mhz"] = reads
+                out["mclk_mhz"] = current("pp_dpm_mclk")
+                out["source"] = "sysfs pp_dpm_sclk/pp_dpm_mclk (level marked current; sclk = the highest of the readings listed)"
                 return out
     except Exception:
         pass

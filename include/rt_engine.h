@@ -190,11 +190,12 @@ typedef struct rt_launch_opts {
                                 tuning builds of the library only (-DRT_TUNING)        */
     int interleave_count;    /* multi-GPU load balance: when > 1 this call renders the
                                 row blocks k = interleave_index, +count, +2*count, ... of
-                                `interleave_rows` rows each (y0/y1 must be 0). Output
-                                buffers are compact: local row L holds global row
-                                ((L / rows) * count + index) * rows + L % rows          */
+                                `interleave_rows` rows each, counted from the first row
+                                of the band [y0, y1) (y0 a multiple of `rows`; 0/0 = the
+                                whole frame). Output buffers are compact: local row L holds
+                                global row y0 + ((L / rows) * count + index) * rows + L % rows */
     int interleave_index;
-    int interleave_rows;     /* block height, a multiple of 16; 0 = 16                 */
+    int interleave_rows;     /* block height, a power of two >= 16; 0 = 16             */
     void *packed24;          /* optional device buffer, 3 bytes per pixel (B,G,R: the packed
                                 word without its zero top byte), width*rows*3 bytes, band-local
                                 like `pixels`; needs width % 4 == 0. What a multi-GPU rank
@@ -449,6 +450,11 @@ int rt_debug_light(const rt_sphere *spheres, int n_spheres, const rt_vec3 *start
  *          low word), out[2] = lanes the 512x512 certainty test accepted, out[3] = accepted
  *          lanes whose texel index differs from the exact one (must be 0)                   */
 int rt_debug_shortcuts(int what, unsigned seed, long long n, unsigned long long out[4]);
+/* The per-sphere occluder lists the culling kernels use for one light (host computation, no GPU): for every sphere i
+ * of the list the number of spheres a shadow ray leaving i's surface towards `light` can hit at all (counts[i]; -1: no
+ * list), the beam slope the list holds for (kcaps[i]) and the list positions of its first `cap` members
+ * (members[i*cap ..]; likeliest occluder first). Tests only.                                                      */
+int rt_debug_occluder_lists(const rt_sphere *spheres, int n, const rt_light *light, int *counts, float *kcaps, int *members, int cap);
 
 #ifdef __cplusplus
 }

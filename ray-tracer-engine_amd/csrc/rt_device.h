@@ -91,6 +91,13 @@ struct RtLightDev {
     float pad0_, pad1_;
 };
 
+struct RtCandHdr {      // one sphere's occluder list for one light (RtFrameAux::cand_hdr)
+    int offset, count;  // entries [offset, offset + count) of the light's entry array; count < 0: no list
+    float kcap;         // largest beam slope the list was built for
+    float pad_;
+};
+#define RT_CAND_CAP 128         // longest occluder list kept (= RT_LIST_CAP: what a wave's LDS list holds)
+
 struct RtPlaneDev {     // plane: a point and the normal as given (kernel.cu:364-367)
     float ox, oy, oz, nx, ny, nz, pad0_, pad1_;
 };
@@ -131,6 +138,14 @@ struct RtFrameAux {
     // {highest axial extent above that point, 3-D radius, -, -}. Null: use `sorted`/`blocks`.
     const float *lsorted[RT_DEV_MAX_LIGHTS];
     const float *lblocks[RT_DEV_MAX_LIGHTS];
+
+    // per light and per SPHERE S, the spheres that a shadow ray leaving S's surface towards that light can hit at all
+    // (host: rt_build_occluder_lists): cand_hdr[light][S] = {offset, count, kcap}, cand_ent[light] + offset = `count`
+    // float4 table entries, likeliest occluder first. A group of pixels whose closest hit is S culls those `count`
+    // entries against its beam in ONE step instead of walking the light's column blocks. count < 0: no list (too long,
+    // non-finite data); valid for beams of slope <= kcap only. Null: no such table.
+    const RtCandHdr *cand_hdr[RT_DEV_MAX_LIGHTS];
+    const float *cand_ent[RT_DEV_MAX_LIGHTS];
 
     // sky texture and skybox sphere (kernel.cu:1116-1166)
     const float *sky_r, *sky_g, *sky_b;

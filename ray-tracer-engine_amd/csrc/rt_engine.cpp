@@ -187,6 +187,14 @@ struct rt_scene {
     // sphere list or a light's position changes
     float4 *d_light_tabs = nullptr;
     size_t cap_light_tabs = 0;           // float4 units
+    // per-light occluder lists (rt_build_occluder_lists): [n_lights][n] headers, then the lights' entry arrays
+    char *d_cand = nullptr;
+    size_t cap_cand = 0;                 // bytes
+    size_t cand_ent_off[RT_MAX_LIGHTS] = {};   // byte offset of light i's entries in d_cand (headers: i * n * 16)
+    bool cand_valid[RT_MAX_LIGHTS] = {};
+    float cand_pos[RT_MAX_LIGHTS][3];    // light position each list set was built for
+    unsigned long long cand_gen = ~0ull;
+    int cand_n_lights = 0;
     unsigned long long sphere_gen = 0;   // bumped whenever the mirrored sphere list changes
     unsigned long long ltab_gen = ~0ull; // sphere_gen the light tables were built from
     int ltab_n_lights = 0;
@@ -226,6 +234,7 @@ struct rt_scene {
 
 static const int kMaxSpheresLds = (160 * 1024 - RT_WAVES_PER_WG * (RT_LIST_CAP * 20 + 16 * 4 + 64 * 4 + RT_BOX_CAP * 4)) / 16;
 static const int kMaxSpheres = 1 << 22;
+static const int kMaxSpheresOccluders = 16384;   // the per-sphere occluder lists are an O(n^2) host build per light
 
 extern "C" rt_scene *rt_scene_create(void)
 {
@@ -304,6 +313,7 @@ extern "C" void rt_scene_destroy(rt_scene *s)
     if (s->d_tri_bs) (void)hipFree(s->d_tri_bs);
     if (s->d_tri_nrm) (void)hipFree(s->d_tri_nrm);
     if (s->d_light_tabs) (void)hipFree(s->d_light_tabs);
+    if (s->d_cand) (void)hipFree(s->d_cand);
     for (TileOrder &o : s->orders)
         if (o.cost) (void)hipFree(o.cost);
     if (s->order_built) (void)hipEventDestroy(s->order_built);
@@ -484,6 +494,60 @@ static int rt_scene_prepare_lights(rt_scene *s, hipStream_t stream)
     RT_HIP(hipStreamSynchronize(stream));   // rare (scene or light change): `h` goes out of scope
     s->ltab_gen = s->sphere_gen;
     s->ltab_n_lights = s->n_lights;
+    s->epoch++;
+    return RT_OK;
+}
+
+// Per-light occluder lists (rt_tables.hip): which spheres a shadow ray from each sphere's surface can hit at all.
+// Host build, O(n^2) per light, when the list or a light's position changes.
+static int rt_scene_prepare_occluders(rt_scene *s, hipStream_t stream)
+{
+    const int n = s->n_spheres;
+    bool want = n >= 64 && n <= kMaxSpheresOccluders && s->h_prev.size() == (size_t)n;
+#ifdef RT_TUNING
+    if (s->tune_no_light_columns) want = false;
+#endif
+    if (!want) {
+        for (int i = 0; i < RT_MAX_LIGHTS; ++i) s->cand_valid[i] = false;
+        s->cand_gen = ~0ull;
+        return RT_OK;
+    }
+    bool same = (s->cand_gen == s->sphere_gen) && (s->cand_n_lights == s->n_lights);
+    for (int i = 0; i < s->n_lights && same; ++i) {
+        const float p[3] = {s->lights[i].pos.x, s->lights[i].pos.y, s->lights[i].pos.z};
+        same = memcmp(p, s->cand_pos[i], sizeof p) == 0;
+    }
+    if (same) return RT_OK;
+    int rc = rt_scene_quiesce(s);   // frames in flight may be reading the old lists
+    if (rc != RT_OK) return rc;
+    std::vector<std::vector<RtCandHdr>> hdr((size_t)s->n_lights);
+    std::vector<std::vector<float4>> ent((size_t)s->n_lights);
+    size_t bytes = sizeof(RtCandHdr) * (size_t)n * (size_t)s->n_lights;
+    for (int i = 0; i < s->n_lights; ++i) {
+        const float p[3] = {s->lights[i].pos.x, s->lights[i].pos.y, s->lights[i].pos.z};
+        memcpy(s->cand_pos[i], p, sizeof p);
+        rt_build_occluder_lists(s->h_prev.data(), n, p, hdr[i], ent[i]);
+        s->cand_ent_off[i] = bytes;
+        bytes += sizeof(float4) * ent[i].size();
+    }
+    if (bytes > s->cap_cand) {
+        if (s->d_cand) RT_HIP(hipFree(s->d_cand));
+        s->d_cand = nullptr;
+        s->cap_cand = 0;
+        RT_HIP(hipMalloc((void **)&s->d_cand, bytes));
+        s->cap_cand = bytes;
+    }
+    std::vector<char> h(bytes);
+    for (int i = 0; i < s->n_lights; ++i) {
+        memcpy(h.data() + sizeof(RtCandHdr) * (size_t)n * (size_t)i, hdr[i].data(), sizeof(RtCandHdr) * (size_t)n);
+        memcpy(h.data() + s->cand_ent_off[i], ent[i].data(), sizeof(float4) * ent[i].size());
+        s->cand_valid[i] = true;
+    }
+    for (int i = s->n_lights; i < RT_MAX_LIGHTS; ++i) s->cand_valid[i] = false;
+    RT_HIP(hipMemcpyAsync(s->d_cand, h.data(), bytes, hipMemcpyHostToDevice, stream));
+    RT_HIP(hipStreamSynchronize(stream));   // rare (scene or light change): `h` goes out of scope
+    s->cand_gen = s->sphere_gen;
+    s->cand_n_lights = s->n_lights;
     s->epoch++;
     return RT_OK;
 }
@@ -966,6 +1030,9 @@ static void rt_build_frame_aux(const rt_scene *s, RtFrameAux *ax)
             const bool on = current && i < s->n_lights && s->ltab_valid[i];
             ax->lsorted[i] = on ? reinterpret_cast<const float *>(s->d_light_tabs + per_light * i) : nullptr;
             ax->lblocks[i] = on ? reinterpret_cast<const float *>(s->d_light_tabs + per_light * i + n_pad) : nullptr;
+            const bool con = s->d_cand && s->cand_gen == s->sphere_gen && s->cand_n_lights == s->n_lights && i < s->n_lights && s->cand_valid[i];
+            ax->cand_hdr[i] = con ? reinterpret_cast<const RtCandHdr *>(s->d_cand + sizeof(RtCandHdr) * (size_t)s->n_spheres * (size_t)i) : nullptr;
+            ax->cand_ent[i] = con ? reinterpret_cast<const float *>(s->d_cand + s->cand_ent_off[i]) : nullptr;
         }
     }
     ax->sky_r = s->d_sky[0]; ax->sky_g = s->d_sky[1]; ax->sky_b = s->d_sky[2];
@@ -1061,11 +1128,14 @@ int rt_build_frame_consts(const rt_scene *s, const rt_frame_desc *fd, const floa
                 (((fd->pixels || o.packed24) && o.resolve >= 0) ? RT_FLAG_RESOLVE : 0) |
                 (o.force_slow_path ? RT_FLAG_FORCE_SLOW : 0) | (s->mesh_has_normals ? RT_FLAG_MESH_NORMALS : 0);
     fc->local_rows = y1 - y0;
+    fc->il_count = 1;      // a contiguous band is the interleave of one rank (the kernel has one row formula)
+    fc->il_index = 0;
+    fc->il_rows = 16;
     if (o.interleave_count > 1) {
         const int b = o.interleave_rows > 0 ? o.interleave_rows : 16;
         // with a row band the blocks are dealt from the band's first row (which must start a block)
-        if (b % 16 != 0 || y0 % b != 0 || o.interleave_index < 0 || o.interleave_index >= o.interleave_count) {
-            rt_set_error("rt_scene_render: bad interleave (count=%d index=%d rows=%d; y0=%d must be a multiple of rows)",
+        if (b < 16 || (b & (b - 1)) != 0 || y0 % b != 0 || o.interleave_index < 0 || o.interleave_index >= o.interleave_count) {
+            rt_set_error("rt_scene_render: bad interleave (count=%d index=%d rows=%d: a power of two >= 16; y0=%d must be a multiple of rows)",
                          o.interleave_count, o.interleave_index, b, y0);
             return RT_ERR_INVALID;
         }
@@ -1183,6 +1253,8 @@ int rt_scene_prepare_static(rt_scene *s, const rt_frame_desc *fd, hipStream_t st
     int rc = RT_OK;
     if (fd->opts.cull != 0) {
         rc = rt_scene_prepare_lights(s, stream);
+        if (rc != RT_OK) return rc;
+        rc = rt_scene_prepare_occluders(s, stream);
         if (rc != RT_OK) return rc;
     }
     const int spp = fd->opts.spp > 0 ? fd->opts.spp : 1;
@@ -1537,6 +1609,31 @@ extern "C" int rt_debug_shortcuts(int what, unsigned seed, long long n, unsigned
     RT_HIP(hipMemset(d.p, 0, sizeof(unsigned long long) * 4));
     RT_HIP(rt_dev_launch_dbg_shortcuts(what, seed, n, d.p, nullptr));
     RT_HIP(hipMemcpy(out, d.p, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// The occluder lists of one light (rt_build_occluder_lists; host only, no GPU): counts[i] = entries of sphere i's list
+// (-1: none), kcaps[i] = the beam slope it holds for, members: n x cap ints, the list positions of the first `cap`
+// members of every list (an entry is identified by its four floats: the first sphere of the table with those).
+extern "C" int rt_debug_occluder_lists(const rt_sphere *spheres, int n, const rt_light *light, int *counts, float *kcaps, int *members, int cap)
+{
+    if (n <= 0 || !spheres || !light || !counts || !kcaps || (cap > 0 && !members)) return RT_ERR_INVALID;
+    std::vector<float4> tab((size_t)n);
+    pack_spheres(spheres, n, tab.data());
+    std::vector<RtCandHdr> hdr;
+    std::vector<float4> ent;
+    const float p[3] = {light->pos.x, light->pos.y, light->pos.z};
+    rt_build_occluder_lists(tab.data(), n, p, hdr, ent);
+    for (int i = 0; i < n; ++i) {
+        counts[i] = hdr[(size_t)i].count;
+        kcaps[i] = hdr[(size_t)i].kcap;
+        for (int k = 0; k < cap; ++k) members[(size_t)i * cap + k] = -1;
+        for (int k = 0; k < hdr[(size_t)i].count && k < cap; ++k) {
+            const float4 e = ent[(size_t)hdr[(size_t)i].offset + k];
+            for (int j = 0; j < n; ++j)
+                if (memcmp(&tab[(size_t)j], &e, sizeof e) == 0) { members[(size_t)i * cap + k] = j; break; }
+        }
+    }
     return RT_OK;
 }
 

@@ -114,6 +114,18 @@ __global__ void rt_dbg_shortcuts(int what, unsigned seed, long long n, unsigned 
                               __builtin_bit_cast(unsigned, ra.y) == __builtin_bit_cast(unsigned, rb.y) &&
                               __builtin_bit_cast(unsigned, ra.z) == __builtin_bit_cast(unsigned, rb.z);
             if (!same) bad += 1;
+            // the same vector with a +-0 z component (castLightRay's rotation axis) through normalise_z0_t
+            V3 c{a.x * sc, b.y * sc, (h3 & 1u) ? 0.f : -0.f}, d = c;   // (a, b are normalised by now: re-scaled)
+            if ((h3 >> 3) % 11u == 0) c.x = d.x = 0.f;
+            const V3 rc = normalise_inplace(c);
+            const V3 rd = normalise_z0_t<1>(d);
+            const bool same0 = __builtin_bit_cast(unsigned, c.x) == __builtin_bit_cast(unsigned, d.x) &&
+                               __builtin_bit_cast(unsigned, c.y) == __builtin_bit_cast(unsigned, d.y) &&
+                               __builtin_bit_cast(unsigned, c.z) == __builtin_bit_cast(unsigned, d.z) &&
+                               __builtin_bit_cast(unsigned, rc.x) == __builtin_bit_cast(unsigned, rd.x) &&
+                               __builtin_bit_cast(unsigned, rc.y) == __builtin_bit_cast(unsigned, rd.y) &&
+                               __builtin_bit_cast(unsigned, rc.z) == __builtin_bit_cast(unsigned, rd.z);
+            if (!same0) bad += 1;
         } else if (what == 2) {
             // unit normals: uniform on the sphere, plus clusters at the poles and the seams
             float z = unit_float(h0) * 2.f - 1.f, phi = unit_float(h1) * 6.2831853f;

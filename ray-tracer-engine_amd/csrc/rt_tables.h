@@ -11,6 +11,14 @@
 
 void rt_build_sorted_blocks(const float4 *tab, int n, float4 *sorted, float4 *blocks, int *orig);
 void rt_build_light_columns(const float4 *tab, int n, const float u[3], float4 *sorted, float4 *blocks);
+// Per sphere S of the table and one light: the entries a shadow ray from S's surface towards the light can hit
+// (see RtFrameAux::cand_hdr). hdr: n records; ent: the concatenated lists.
+#include <vector>
+struct RtCandHdr;
+void rt_build_occluder_lists(const float4 *tab, int n, const float lpos[3], std::vector<RtCandHdr> &hdr, std::vector<float4> &ent);
+// Slope of the beam the frame kernel gives a group of shadow rays that start at `start` (binary64 restatement of the
+// kernel's bound; NaN when it has none).
+double rt_light_beam_slope(const double lpos[3], const double start[3]);
 void rt_build_eye_cones_host(const float4 *tab, int n, const float org[3], float4 *sorted, float4 *blocks, int *orig);
 
 size_t rt_eye_cones_size(int n);   // float4 units: [n_pad entries][2 per block][n_pad ints]

@@ -251,6 +251,110 @@ void rt_build_light_columns(const float4 *tab, int n, const float u_f[3], float4
 }
 
 // ---------------------------------------------------------------------------
+// Occluder lists. A shadow ray of castLightRay (kernel.cu:1438-1510) starts a hair above the surface it shades and
+// runs within a few degrees of u = l.pos/|l.pos| WHATEVER its start (kernel.cu:1468 forms the direction relative to the
+// world origin). So the spheres such a ray can hit from anywhere on sphere S are those that reach into the cone of
+// slope kcap around u from a ball around S: a short list per (S, light), built here once per scene, of which a tile
+// then only has to cull the members against its own, much thinner beam (rt_trace.inc: build_list_cand) instead of
+// walking the light's column blocks. Conservative by the same member test the kernel applies (beam_member_test) with
+// the ball of S (radius R_S 1.001 + 1e-3: the starts lie 1e-5 above the surface, give or take the rounding of the hit
+// point) as the ray origins; kcap = 1.15 x the largest slope the kernel's own bound yields at 14 points of S, and the
+// kernel checks its beam's slope against it before using the list.
+// ---------------------------------------------------------------------------
+double rt_light_beam_slope(const double lpos[3], const double start[3])
+{
+    const double L = std::sqrt(lpos[0] * lpos[0] + lpos[1] * lpos[1] + lpos[2] * lpos[2]);
+    double t[3] = {lpos[0] - start[0], lpos[1] - start[1], lpos[2] - start[2]};
+    const double tl = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+    if (!(L > 0) || !(tl > 0) || !std::isfinite(L + tl)) return NAN;
+    for (double &v : t) v /= tl;
+    const double u[3] = {lpos[0] / L, lpos[1] / L, lpos[2] / L};
+    // an orthonormal pair across u (any will do: the singular value does not depend on it)
+    const int k = (std::fabs(u[0]) <= std::fabs(u[1]) && std::fabs(u[0]) <= std::fabs(u[2])) ? 0 : (std::fabs(u[1]) <= std::fabs(u[2]) ? 1 : 2);
+    double e1[3] = {-u[k] * u[0], -u[k] * u[1], -u[k] * u[2]};
+    e1[k] += 1.0;
+    const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    for (double &v : e1) v /= l1;
+    const double e2[3] = {u[1] * e1[2] - u[2] * e1[1], u[2] * e1[0] - u[0] * e1[2], u[0] * e1[1] - u[1] * e1[0]};
+    const double c = t[2], sn = std::sqrt(std::max(1.0 - c * c, 0.0)), q2 = t[0] * t[0] + t[1] * t[1];
+    double kmax2, frob2;
+    if (q2 < 1.0e-4) {
+        kmax2 = frob2 = 6.0;
+    } else {
+        const double rq = 1.0 / std::sqrt(q2), ax = -t[1] * rq, ay = t[0] * rq, omc = 1.0 - c;
+        const double M[3][3] = {{c + ax * ax, ax * ay * omc, -ay * sn}, {ax * ay * omc, c + ay * ay * omc, -ax * sn}, {-ay * sn, ax * sn, c}};
+        double p[3], q[3];
+        frob2 = 0;
+        for (int i = 0; i < 3; ++i) {
+            p[i] = M[i][0] * e1[0] + M[i][1] * e1[1] + M[i][2] * e1[2];
+            q[i] = M[i][0] * e2[0] + M[i][1] * e2[1] + M[i][2] * e2[2];
+            frob2 += M[i][0] * M[i][0] + M[i][1] * M[i][1] + M[i][2] * M[i][2];
+        }
+        const double h11 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2], h22 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+        const double h12 = p[0] * q[0] + p[1] * q[1] + p[2] * q[2], hd = 0.5 * (h11 - h22);
+        kmax2 = (0.5 * (h11 + h22) + std::sqrt(hd * hd + h12 * h12)) * 1.001;
+    }
+    const double den = L - std::sqrt(frob2) * 1.001;
+    if (!(den > 0.05 * L)) return NAN;
+    const double s2 = kmax2 / (den * den) * 1.0001;
+    if (!(s2 < 0.25)) return NAN;
+    const double snw = std::sqrt(s2) * (double)RT_SPREAD_MUL + (double)RT_SPREAD_ADD;
+    return snw / std::sqrt(std::max(1.0 - snw * snw, 0.05));
+}
+
+void rt_build_occluder_lists(const float4 *tab, int n, const float lpos_f[3], std::vector<RtCandHdr> &hdr, std::vector<float4> &ent)
+{
+    hdr.assign((size_t)n, RtCandHdr{0, -1, 0.f, 0.f});
+    ent.clear();
+    const double lpos[3] = {lpos_f[0], lpos_f[1], lpos_f[2]};
+    const double L = std::sqrt(lpos[0] * lpos[0] + lpos[1] * lpos[1] + lpos[2] * lpos[2]);
+    if (!(L > 0) || !std::isfinite(L)) return;
+    const double u[3] = {lpos[0] / L, lpos[1] / L, lpos[2] / L};
+    std::vector<char> fin((size_t)n);
+    for (int i = 0; i < n; ++i) fin[i] = std::isfinite(tab[i].x) && std::isfinite(tab[i].y) && std::isfinite(tab[i].z) && std::isfinite(tab[i].w) && tab[i].w >= 0;
+    std::vector<std::pair<double, int>> keep;
+    static const double dirs[14][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}, {1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {1, -1, -1},
+                                       {-1, 1, 1}, {-1, 1, -1}, {-1, -1, 1}, {-1, -1, -1}};
+    for (int si = 0; si < n; ++si) {
+        if (!fin[si]) continue;
+        const double c[3] = {tab[si].x, tab[si].y, tab[si].z}, R = std::sqrt((double)tab[si].w);
+        double kmax = 0;
+        bool usable = true;
+        for (const double *d : dirs) {
+            const double dl = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            const double st[3] = {c[0] + R * d[0] / dl, c[1] + R * d[1] / dl, c[2] + R * d[2] / dl};
+            const double k = rt_light_beam_slope(lpos, st);
+            if (!(k == k)) { usable = false; break; }
+            kmax = std::max(kmax, k);
+        }
+        if (!usable) continue;
+        const double kcap = kmax * 1.15 + 1.0e-4;
+        const double r0 = R * 1.001 + 1.0e-3, smin = -r0;
+        keep.clear();
+        bool all_finite = true;
+        for (int ti = 0; ti < n && all_finite; ++ti) {
+            if (!fin[ti]) { all_finite = false; break; }   // a non-finite entry can return anything to the exact test: no list
+            const double v[3] = {tab[ti].x - c[0], tab[ti].y - c[1], tab[ti].z - c[2]};
+            const double vv = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], sa = v[0] * u[0] + v[1] * u[1] + v[2] * u[2];
+            const double d2 = std::max(vv - sa * sa, 0.0);
+            const double pad = (double)RT_PAD_REL * (vv + r0 * r0) * 1.001 + (double)RT_PAD_ABS * 1.001;
+            const double rc = std::sqrt((double)tab[ti].w + pad) * 1.0002;
+            const double reach = sa + rc - smin;
+            const double rad = kcap * std::max(reach, 0.0) + r0 + rc;
+            if (reach >= 0 && d2 <= rad * rad * 1.001) keep.push_back({std::sqrt(d2) - std::sqrt((double)tab[ti].w), ti});
+        }
+        if (!all_finite || (int)keep.size() > RT_CAND_CAP) continue;
+        std::sort(keep.begin(), keep.end());   // likeliest occluder first: reaches farthest across S's own axis
+        hdr[si].offset = (int)ent.size();
+        hdr[si].count = (int)keep.size();
+        hdr[si].kcap = (float)(kcap * 0.9999);
+        for (const auto &kv : keep) ent.push_back(tab[kv.second]);
+    }
+    ent.resize((ent.size() + 63) & ~(size_t)63, make_float4(0.f, 0.f, 0.f, 0.f));   // a wave may read a whole step past a list's end
+    if (ent.empty()) ent.resize(64, make_float4(0.f, 0.f, 0.f, 0.f));
+}
+
+// ---------------------------------------------------------------------------
 // Eye cones. Every primary ray starts at the same point O, so the table is ordered by the
 // direction of the centres as seen from O (octahedral map, 2-D Morton) and cut into blocks of
 // RT_BLOCK: cones from O that a tile's thin beam meets far less often than the cubes of the

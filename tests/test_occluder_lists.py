@@ -1,0 +1,70 @@
+"""The per-sphere occluder lists (rt_tables.hip: rt_build_occluder_lists) against what they stand for: for every light
+of the reference and random points on random spheres S of the BASELINE scenes, every sphere that one of the ten shadow
+rays of castLightRay (kernel.cu:1438-1510; directions from the oracle, the binary32 test restated with numpy below)
+hits must be a member of S's list. Host computation only: runs without a GPU. (That a tile's cull of such a list loses
+nothing either is what the culled == brute-force frame tests check on the GPU.)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+f32 = np.float32
+
+
+def _hits(tab, org, d):
+    """sphere::intersect (kernel.cu:332-353) of ONE ray against every table entry {cx,cy,cz,radius^2}, binary32."""
+    with np.errstate(all="ignore"):
+        oc = (org[None, :] - tab[:, :3]).astype(f32)
+        A = f32(f32(f32(d[0] * d[0]) + f32(d[1] * d[1])) + f32(d[2] * d[2]))
+        h = ((d[0] * oc[:, 0]).astype(f32) + (d[1] * oc[:, 1]).astype(f32)).astype(f32)
+        h = (h + (d[2] * oc[:, 2]).astype(f32)).astype(f32)
+        B = (f32(2) * h).astype(f32)
+        Cq = ((oc[:, 0] * oc[:, 0]).astype(f32) + (oc[:, 1] * oc[:, 1]).astype(f32)).astype(f32)
+        Cq = ((Cq + (oc[:, 2] * oc[:, 2]).astype(f32)).astype(f32) - tab[:, 3]).astype(f32)
+        disc = ((B * B).astype(f32) - ((f32(4) * A) * Cq).astype(f32)).astype(f32)
+        sq = np.sqrt(disc).astype(f32)
+        t = ((-B + sq).astype(f32) / f32(f32(2) * A)).astype(f32)
+        return (t == 0) | (t.astype(np.float64) >= 0.0001)
+
+
+@pytest.mark.parametrize("n", [256, 1024])
+def test_occluder_lists_contain_every_sphere_a_shadow_ray_hits(rt, oracle, n):
+    lib = rt.load_library()
+    olib = oracle.load()
+    sph = rt.generate_spheres(n, 1)
+    tab = np.array([[s.orgin.x, s.orgin.y, s.orgin.z, f32(s.radius) * f32(s.radius)] for s in sph], dtype=np.float32)
+    lights = rt.default_lights()
+    rng = np.random.default_rng(7)
+    cap = 128
+    for li in range(3):
+        counts = (C.c_int * n)()
+        kcaps = (C.c_float * n)()
+        members = (C.c_int * (n * cap))()
+        assert lib.rt_debug_occluder_lists(sph, n, C.byref(lights[li]), counts, kcaps, members, cap) == 0
+        cnt = np.array(counts[:])
+        mem = np.array(members[:]).reshape(n, cap)
+        assert (cnt >= 0).mean() > 0.9, (cnt >= 0).mean()                 # nearly every sphere has a list
+        assert cnt.max() <= cap and np.median(cnt[cnt >= 0]) < 64
+        olight = oracle.OLight(oracle.OVec3(lights[li].pos.x, lights[li].pos.y, lights[li].pos.z), lights[li].size, 1, 1, 1)
+        checked = 0
+        for _ in range(150):
+            si = int(rng.integers(0, n))
+            if cnt[si] < 0 or tab[si, 3] <= 0:
+                continue
+            R = np.sqrt(np.float64(tab[si, 3]))
+            dirn = rng.normal(size=3)
+            dirn /= np.linalg.norm(dirn)
+            p = (tab[si, :3].astype(np.float64) + dirn * R).astype(np.float32)
+            start = (dirn.astype(np.float32) * f32(0.00001) + p).astype(np.float32)   # kernel.cu:1647
+            dirs = (C.c_float * 30)()
+            st = oracle.OVec3(*[float(v) for v in start])
+            olib.oracle_light_dirs(C.byref(st), C.byref(olight), dirs)
+            d = np.array(dirs[:], dtype=np.float32).reshape(10, 3)
+            listed = set(int(v) for v in mem[si, :cnt[si]])
+            assert si in listed                                           # a sphere can always shadow itself
+            for j in range(10):
+                hit = np.nonzero(_hits(tab, start, d[j]))[0]
+                missing = [int(k) for k in hit if int(k) not in listed]
+                assert not missing, (n, li, si, j, missing)
+                checked += len(hit)
+        assert checked > 100

@@ -14,20 +14,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ray-tracer-engine_amd", "csrc")
 LLVM = "/opt/rocm/lib/llvm/bin"
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-fno-slp-vectorize", "-g"]
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-fno-slp-vectorize", "-g", "-DRT_QUICK"]
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--inst", default="ILi8ELb1ELi0ELb1ELb0E")
+    ap.add_argument("--inst", default="ILi8ELb1ELi0ELb0ELi0ELb0E")
     ap.add_argument("--by-callee", action="store_true")
     ap.add_argument("--top", type=int, default=60)
     a = ap.parse_args()
     tmp = tempfile.mkdtemp(prefix="rt_attrib_")
     obj, co = os.path.join(tmp, "k.o"), os.path.join(tmp, "k.co")
-    subprocess.check_call(["hipcc", *FLAGS, "-x", "hip", "--cuda-device-only", "-c", "-o", obj,
+    subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, "-x", "hip", "--cuda-device-only", "--no-gpu-bundle-output", "-c", "-o", co,
                            os.path.join(CSRC, "rt_kernels.hip")], stderr=subprocess.DEVNULL)
-    subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={obj}",
-                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
     syms = subprocess.check_output([f"{LLVM}/llvm-readelf", "-sW", co], text=True)
     sym = [l.split()[-1] for l in syms.splitlines()
            if "rt_trace_tiles" + a.inst in l and " FUNC " in l][0]
@@ -55,7 +53,7 @@ def main():
                "lds" if op.startswith("ds_") else "mem")
         key = (outer_line, callee) if a.by_callee else outer_line
         per[key] += 1; kinds[key][cls] += 1
-    src = open(os.path.join(CSRC, "rt_kernels.hip")).read().splitlines()
+    src = open(os.path.join(CSRC, "rt_trace.inc")).read().splitlines()
     tot = collections.Counter()
     for k in kinds: tot.update(kinds[k])
     print(f"{sym}: {len(insts)} instructions: {dict(tot)}")
