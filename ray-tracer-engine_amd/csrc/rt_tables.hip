@@ -279,7 +279,7 @@ double rt_light_beam_slope(const double lpos[3], const double start[3])
     const double c = t[2], sn = std::sqrt(std::max(1.0 - c * c, 0.0)), q2 = t[0] * t[0] + t[1] * t[1];
     double kmax2, frob2;
     if (q2 < 1.0e-4) {
-        kmax2 = frob2 = 6.0;
+        kmax2 = frob2 = 8.0;     // as the kernel
     } else {
         const double rq = 1.0 / std::sqrt(q2), ax = -t[1] * rq, ay = t[0] * rq, omc = 1.0 - c;
         const double M[3][3] = {{c + ax * ax, ax * ay * omc, -ay * sn}, {ax * ay * omc, c + ay * ay * omc, -ax * sn}, {-ay * sn, ax * sn, c}};

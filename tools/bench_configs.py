@@ -11,6 +11,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import rt_amd
+from _settle import settle
 
 rt = rt_amd.load()
 lib = rt.load_library()
@@ -23,8 +24,7 @@ def time_render(scene, w, h, iters=30, **kw):
     pk = torch.empty((rows, w), dtype=torch.int32, device="cuda")
     fd = scene.frame_desc(w, h, pixels=pk.data_ptr(), rgba=rgba.data_ptr(), **kw)
     st = torch.cuda.current_stream()
-    for _ in range(3):
-        scene.render_raw(fd, st.cuda_stream)
+    settle(lambda: scene.render_raw(fd, st.cuda_stream), torch.cuda.synchronize)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
@@ -55,11 +55,9 @@ fd = s1024.frame_desc(w, h, pixels=pk.data_ptr(), rgba=acc.data_ptr())
 for with_copy in (False, True):
     g = lib.rt_graph_capture(s1024.handle, C.byref(fd), 4, host.data_ptr() if with_copy else None, stream.cuda_stream)
     assert g, lib.rt_last_error()
-    for _ in range(3):
-        lib.rt_graph_launch(g, stream.cuda_stream)
-    stream.synchronize()
+    settle(lambda: lib.rt_graph_launch(g, stream.cuda_stream), stream.synchronize, window=5)
     t0 = time.perf_counter()
-    n = 10
+    n = 20
     for _ in range(n):
         lib.rt_graph_launch(g, stream.cuda_stream)
     stream.synchronize()
@@ -108,8 +106,7 @@ out["C5_scaled_extent_whole_frame_on_1_gpu"] = {"ms": ms, "Mrays_per_s": 7680 * 
 lib.rt_config_set_sphere_count(1024)
 lib.rt_on_start()
 lib.rt_offscreen_resize(3840, 2160)
-for _ in range(3):
-    lib.rt_update()
+settle(lib.rt_update, lambda: None, window=5)
 t0 = time.perf_counter()
 n = 20
 for _ in range(n):

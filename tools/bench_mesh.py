@@ -5,6 +5,7 @@ sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.
 import torch
 import rt_amd
 import meshes
+from _settle import settle
 
 rt = rt_amd.load()
 out = {}
@@ -17,11 +18,10 @@ for (w, h, n, lat, lon) in ((1920, 1080, 256, 24, 40), (3840, 2160, 1024, 48, 80
     pk = torch.empty((h, w), dtype=torch.int32, device="cuda")
     fd = scene.frame_desc(w, h, pixels=pk.data_ptr(), rgba=rgba.data_ptr())
     st = torch.cuda.current_stream()
-    for _ in range(2):
-        scene.render_raw(fd, st.cuda_stream)
+    settle(lambda: scene.render_raw(fd, st.cuda_stream), torch.cuda.synchronize, window=5)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    it = 5
+    it = 20
     for _ in range(it):
         scene.render_raw(fd, st.cuda_stream)
     e1.record()
