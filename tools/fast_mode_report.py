@@ -6,6 +6,7 @@ north_star's tolerance is 1e-5 relative per channel; BASELINE.md asks for the fl
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, rt_amd
+from _settle import settle
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--width", type=int, default=3840)
@@ -23,9 +24,7 @@ def timed(fast):
     pk = torch.empty((h, w), dtype=torch.int32, device="cuda")
     fd = scene.frame_desc(w, h, pixels=pk.data_ptr(), rgba=rgba.data_ptr(), fast=fast)
     st = torch.cuda.current_stream()
-    for _ in range(10):
-        scene.render_raw(fd, st.cuda_stream)
-    torch.cuda.synchronize()
+    settle(lambda: scene.render_raw(fd, st.cuda_stream), torch.cuda.synchronize)
     import time
     t0 = time.perf_counter()
     for _ in range(a.steps):

@@ -5,6 +5,7 @@ ms_per_step stays close to kernel_ms the launch path will not limit multi-GPU sc
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, rt_amd
+from _settle import settle
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--world", type=int, nargs="+", default=[1, 2, 4, 8])
@@ -26,9 +27,12 @@ for world in a.world:
                for _ in range(ns)]
     fds = [scene.frame_desc(w, h, pixels=packeds[k].data_ptr(), rgba=rgbas[k].data_ptr(), y0=0, y1=0 if world > 1 else h,
                             spp=1, cull=True, tile=0, interleave=il) for k in range(ns)]
-    for k in range(20):
-        scene.render_raw(fds[k % ns], streams[k % ns].cuda_stream)
-    torch.cuda.synchronize()
+    kk = [0]
+
+    def one():
+        scene.render_raw(fds[kk[0] % ns], streams[kk[0] % ns].cuda_stream)
+        kk[0] += 1
+    settle(one, torch.cuda.synchronize, window=20)
     t0 = time.perf_counter()
     for k in range(a.steps):
         scene.render_raw(fds[k % ns], streams[k % ns].cuda_stream)

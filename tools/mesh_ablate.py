@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import torch
 import rt_amd
+from _settle import settle
 import meshes
 
 rt = rt_amd.load()
@@ -22,15 +23,14 @@ def run(ablate, with_mesh=True, stats=False):
     pk = torch.empty((H, W), dtype=torch.int32, device="cuda")
     fd = scene.frame_desc(W, H, pixels=pk.data_ptr(), rgba=rgba.data_ptr())
     st = torch.cuda.current_stream()
-    for _ in range(2):
-        scene.render_raw(fd, st.cuda_stream)
+    settle(lambda: scene.render_raw(fd, st.cuda_stream), torch.cuda.synchronize, window=5)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(5):
+    for _ in range(20):
         scene.render_raw(fd, st.cuda_stream)
     e1.record()
     torch.cuda.synchronize()
-    res = {"ms": round(e0.elapsed_time(e1) / 5, 4)}
+    res = {"ms": round(e0.elapsed_time(e1) / 20, 4)}
     if stats:
         res["stats"] = scene.render(W, H, want_stats=True)["stats"]
     return res

@@ -5,6 +5,7 @@ durations the kernel records), for the whole frame and for one rank's share of 1
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, rt_amd
+from _settle import settle
 
 rt = rt_amd.load()
 lib = rt.load_library()
@@ -21,8 +22,7 @@ for world in (1, 2, 4, 8):
     st = torch.cuda.current_stream()
 
     def timed(steps=200):
-        for _ in range(10):
-            scene.render_raw(fd, st.cuda_stream)
+        settle(lambda: scene.render_raw(fd, st.cuda_stream), torch.cuda.synchronize)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(steps):
