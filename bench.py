@@ -396,25 +396,33 @@ def main():
     sync_main = make_sync(streams)
     # untimed pre-roll until the clock has settled under this workload (the timed region stays `steps` frames after
     # `warmup` more); clocks read while launches are in flight, before and at the end of the timed loop
-    k0, pre = preroll(step_main, sync_main, reduce_max) if not args.no_preroll else (0, None)
     clocks = {}
-    if rank == 0:
+    k0 = 0
+    if not args.no_preroll:
         for _ in range(50):
             step_main(k0, None)
             k0 += 1
-        clocks["before"] = read_clocks(fast_only=not args.smi_clocks)
+        if rank == 0:
+            clocks["before"] = read_clocks(fast_only=not args.smi_clocks)
         sync_main(k0)
-    elif world > 1:
-        for _ in range(50):
-            step_main(k0, None)
-            k0 += 1
-        sync_main(k0)
-    elapsed, k, c_end = timed_loop(step_main, args.steps, args.warmup, sync_main, world, k0=k0,
-                                   mid=(lambda: read_clocks(fast_only=True)) if rank == 0 else None)
+    # (the pre-roll comes AFTER the clock reading: a query of the power controller disturbs the launches around it)
+    pre = None
+    if not args.no_preroll:
+        kpre, pre = preroll(lambda k, i: step_main(k0 + k, i), lambda k: sync_main(k0 + k), reduce_max)
+        k0 += kpre
+    # (no clock reading inside the timed region: a read of the power controller's tables takes a millisecond or two and was
+    # measured to stretch a 20-step loop by 17 %; the clocks are read during untimed launches right before and right after)
+    elapsed, k, _ = timed_loop(step_main, args.steps, args.warmup, sync_main, world, k0=k0)
+    kk = k
+    for _ in range(50):
+        step_main(kk, None)
+        kk += 1
     if rank == 0:
-        clocks["end_of_timed_loop"] = c_end
-    packed = packed2[(k - 1) & 1]
-    rgba = rgba2[(k - 1) & 1]
+        clocks["after"] = read_clocks(fast_only=True)
+    sync_main(kk)
+    packed = packed2[(kk - 1) & 1]
+    rgba = rgba2[(kk - 1) & 1]
+    k = kk
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     gather_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_g])) if ev_g else 0.0
     # per-rank figures ("report per-GPU kernel times"): every rank's own launch duration and loop time
@@ -550,7 +558,8 @@ def main():
                        "outputs": "float4 RGBA + packed 0x00RRGGBB in HBM"},
             "kernel_ms": kernel_ms,
             "clocks": {**clocks, "nominal_sclk_mhz": 2400,
-                       "note": "read while launches of this workload were in flight (an idle GPU reports its idle clock); "
+                       "note": "read during 50 untimed launches of this workload right before and right after the timed region "
+                               "(an idle GPU reports its idle clock; a read inside the region would stretch it); "
                                "every fraction of a peak in this line is against the NOMINAL peak (8 TB/s, 157.3 TFLOP/s, "
                                "2.4 GHz issue), not scaled to the clock read here"},
             "preroll": pre,

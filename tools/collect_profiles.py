@@ -8,10 +8,12 @@ json.dump(json.loads(line), open(f"profiles/{name}_bench_c3_n1.json", "w"), inde
 subprocess.check_call([sys.executable, "tools/summarize_profile.py", tag, f"{name}_c3_frame_kernel"], stdout=subprocess.DEVNULL)
 subprocess.check_call([sys.executable, "tools/summarize_profile.py", tag + "_tablds", f"{name}_c3_table_lds"], stdout=subprocess.DEVNULL)
 for f in ("other_configs", "mesh_scenes", "fast_mode", "host_overhead_single_stream", "host_overhead_two_streams",
-          "multi_one_gpu_rehearsal"):
+          "multi_one_gpu_rehearsal", "build_and_first_launch", "bench_driver_flags", "bench_n2_gloo_one_gpu"):
     s = open(os.path.join(src, f + ".json")).read()
     open(f"profiles/{name}_{f}.json", "w").write(s[s.index("{"):])   # (RCCL prints a banner to stdout)
 shutil.copy(os.path.join(src, "ablation_pmc.txt"), f"profiles/{name}_ablation_pmc.txt")
+if os.path.exists(os.path.join(src, "pmc_classes.txt")):
+    shutil.copy(os.path.join(src, "pmc_classes.txt"), f"profiles/{name}_pmc_instruction_classes.txt")
 abl = json.load(open(os.path.join(src, "mesh_ablate.json")))
 json.dump({"scene": "3840x2160, 1024 spheres + uv-sphere mesh of 7520 triangles / 756 leaves (tools/bench_mesh.py)",
            "ms_with_parts_skipped_tuning_build": {k: v["ms"] for k, v in abl.items()},
