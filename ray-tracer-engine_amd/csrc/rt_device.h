@@ -58,11 +58,14 @@
 #endif
 #ifndef RT_MIN_WAVES_ONE_SAMPLE
 #define RT_MIN_WAVES_ONE_SAMPLE 7 // the one-sample kernels without a mesh (every BASELINE config at 1 spp, and each pass of the
-                               // hipGraph frame) fit 72 registers without a spill (compiled without the SLP vectoriser, see
-                               // the Makefile): 7 waves per SIMD. (Their work-counter builds get RT_MIN_WAVES_PER_SIMD.)
+                               // hipGraph frame) at 72 registers = 7 waves per SIMD (compiled without the SLP vectoriser and
+                               // without machine LICM, see the Makefile). With round 3's sample pre-pass the sphere-only
+                               // kernel wants 75: at 7 waves two registers live in scratch (one store, two loads per tile),
+                               // which measures 4.5 % faster than the clean allocation at 6 waves (0.2695 against 0.2818 ms).
+                               // (Their work-counter builds get RT_MIN_WAVES_PER_SIMD.)
 #endif
 #ifndef RT_MIN_WAVES_MESH
-#define RT_MIN_WAVES_MESH 5      // one-sample kernels with the triangle-mesh branches: 89 of 96 registers, no spill
+#define RT_MIN_WAVES_MESH 6      // one-sample kernels with the triangle-mesh branches: 76 of 80 registers, no spill (round 2: 89 at 5 waves)
 #endif
 #ifndef RT_MIN_WAVES_MESH_MULTI
 #define RT_MIN_WAVES_MESH_MULTI 4 // ... with a sample loop or work counters on top: 128 registers, no spill

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ray-tracer-engine_amd", "csrc")
 LLVM = "/opt/rocm/lib/llvm/bin"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-fno-slp-vectorize"]
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-fno-slp-vectorize", "-mllvm", "-disable-machine-licm"]
 KEYS = ("kernarg_segment_size", "private_segment_fixed_size", "sgpr_count", "sgpr_spill_count", "vgpr_count",
         "vgpr_spill_count", "group_segment_fixed_size")
 

@@ -13,3 +13,5 @@ print("walks", v[17], "no_penumbra", v[18], "penumbra lanes", v[19], "lit lanes 
 print("fraction of walked lights without any penumbra lane:", v[18] / v[17], " mean penumbra lanes per walk:", v[19] / v[17], " of lit lanes", v[20] / v[17])
 print("walked lights whose lit lanes are ALL fully shadowed:", v[21], " ALL fully lit:", v[22])
 print("shadow list length histogram (<=1,<=2,<=4,<=8,<=16,<=cap, all clear, full occluder):", v[8:16])
+print("pre-pass: walks that needed the exact chain:", v[23] >> 32, " samples evaluated exactly (wave level):", v[23] & 0xffffffff,
+      " = per such walk", (v[23] & 0xffffffff) / max(1, v[23] >> 32))

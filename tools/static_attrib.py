@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ray-tracer-engine_amd", "csrc")
 LLVM = "/opt/rocm/lib/llvm/bin"
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-fno-slp-vectorize", "-g", "-DRT_QUICK"]
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-fno-slp-vectorize", "-mllvm", "-disable-machine-licm", "-g", "-DRT_QUICK"]
 
 def main():
     ap = argparse.ArgumentParser()
