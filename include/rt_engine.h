@@ -441,6 +441,9 @@ int rt_debug_intersect(const rt_sphere *spheres, const rt_ray *rays, int n, int 
 int rt_debug_light(const rt_sphere *spheres, int n_spheres, const rt_vec3 *start,
                    const rt_vec3 *normal, const rt_light *light, int n,
                    float *dirs /* n*30 */, float *brightness /* n */);
+/* The exact sample directions (n*30) next to the approximate ones of the frame kernel's sample pre-pass (n*30) and the
+ * pre-pass's guard flags (n*10: 1 = the approximate direction may be used), for its error bound (tests only).   */
+int rt_debug_light_prepass(const rt_vec3 *start, const rt_light *light, int n, float *dirs, float *approx_dirs, int *approx_ok);
 /* The culling kernels' shortcuts against the long forms they stand for, evaluated on the
  * device for n pseudo-random inputs derived from `seed` (tests only):
  *  what 0: lean normalise vs the IEEE one on vectors of every scale -> out[0] = differing results
@@ -455,6 +458,10 @@ int rt_debug_shortcuts(int what, unsigned seed, long long n, unsigned long long 
  * list), the beam slope the list holds for (kcaps[i]) and the list positions of its first `cap` members
  * (members[i*cap ..]; likeliest occluder first). Tests only.                                                      */
 int rt_debug_occluder_lists(const rt_sphere *spheres, int n, const rt_light *light, int *counts, float *kcaps, int *members, int cap);
+/* ... plus every list's offset into the light's entry array (offsets[i], or NULL) and the number of entries that array is
+ * allocated with (the kernel reads whole steps of 64 entries from a list's offset on)                                     */
+int rt_debug_occluder_lists_ex(const rt_sphere *spheres, int n, const rt_light *light, int *counts, float *kcaps, int *members, int cap,
+                               int *offsets, int *entries_allocated);
 
 #ifdef __cplusplus
 }

@@ -205,7 +205,10 @@ def load_library():
         "rt_debug_intersect": (ci, [C.POINTER(Sphere), C.POINTER(Ray), ci, C.POINTER(ci), fp]),
         "rt_debug_light": (ci, [C.POINTER(Sphere), ci, C.POINTER(Vec3), C.POINTER(Vec3), C.POINTER(Light), ci, fp, fp]),
         "rt_debug_shortcuts": (ci, [ci, C.c_uint, C.c_longlong, C.POINTER(C.c_ulonglong)]),
+        "rt_debug_light_prepass": (ci, [C.POINTER(Vec3), C.POINTER(Light), ci, fp, fp, C.POINTER(ci)]),
         "rt_debug_occluder_lists": (ci, [C.POINTER(Sphere), ci, C.POINTER(Light), C.POINTER(ci), fp, C.POINTER(ci), ci]),
+        "rt_debug_occluder_lists_ex": (ci, [C.POINTER(Sphere), ci, C.POINTER(Light), C.POINTER(ci), fp, C.POINTER(ci), ci,
+                                            C.POINTER(ci), C.POINTER(ci)]),
         "rt_multi_create": (vp, [ci]),
         "rt_multi_create_ex": (ci, [C.POINTER(ci), ci, ci, C.POINTER(vp)]),
         "rt_multi_destroy": (None, [vp]),

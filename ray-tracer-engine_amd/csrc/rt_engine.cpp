@@ -34,7 +34,7 @@ extern "C" hipError_t rt_dev_launch_dbg_intersect(const float4 *tab, const float
                                                   float *t, hipStream_t stream);
 extern "C" hipError_t rt_dev_launch_dbg_light(const RtFrameConsts *fc, const float4 *tab, const float *starts,
                                               const float *normals, int light_index, int n, float *dirs,
-                                              float *bright, hipStream_t stream);
+                                              float *bright, float *adirs, int *aok, hipStream_t stream);
 
 // ---------------------------------------------------------------------------
 // errors
@@ -1615,7 +1615,8 @@ extern "C" int rt_debug_shortcuts(int what, unsigned seed, long long n, unsigned
 // The occluder lists of one light (rt_build_occluder_lists; host only, no GPU): counts[i] = entries of sphere i's list
 // (-1: none), kcaps[i] = the beam slope it holds for, members: n x cap ints, the list positions of the first `cap`
 // members of every list (an entry is identified by its four floats: the first sphere of the table with those).
-extern "C" int rt_debug_occluder_lists(const rt_sphere *spheres, int n, const rt_light *light, int *counts, float *kcaps, int *members, int cap)
+extern "C" int rt_debug_occluder_lists_ex(const rt_sphere *spheres, int n, const rt_light *light, int *counts, float *kcaps, int *members, int cap,
+                                          int *offsets, int *entries_allocated)
 {
     if (n <= 0 || !spheres || !light || !counts || !kcaps || (cap > 0 && !members)) return RT_ERR_INVALID;
     std::vector<float4> tab((size_t)n);
@@ -1624,9 +1625,11 @@ extern "C" int rt_debug_occluder_lists(const rt_sphere *spheres, int n, const rt
     std::vector<float4> ent;
     const float p[3] = {light->pos.x, light->pos.y, light->pos.z};
     rt_build_occluder_lists(tab.data(), n, p, hdr, ent);
+    if (entries_allocated) *entries_allocated = (int)ent.size();
     for (int i = 0; i < n; ++i) {
         counts[i] = hdr[(size_t)i].count;
         kcaps[i] = hdr[(size_t)i].kcap;
+        if (offsets) offsets[i] = hdr[(size_t)i].offset;
         for (int k = 0; k < cap; ++k) members[(size_t)i * cap + k] = -1;
         for (int k = 0; k < hdr[(size_t)i].count && k < cap; ++k) {
             const float4 e = ent[(size_t)hdr[(size_t)i].offset + k];
@@ -1635,6 +1638,11 @@ extern "C" int rt_debug_occluder_lists(const rt_sphere *spheres, int n, const rt
         }
     }
     return RT_OK;
+}
+
+extern "C" int rt_debug_occluder_lists(const rt_sphere *spheres, int n, const rt_light *light, int *counts, float *kcaps, int *members, int cap)
+{
+    return rt_debug_occluder_lists_ex(spheres, n, light, counts, kcaps, members, cap, nullptr, nullptr);
 }
 
 extern "C" int rt_debug_intersect(const rt_sphere *spheres, const rt_ray *rays, int n, int *hit, float *t)
@@ -1656,9 +1664,9 @@ extern "C" int rt_debug_intersect(const rt_sphere *spheres, const rt_ray *rays, 
     return RT_OK;
 }
 
-extern "C" int rt_debug_light(const rt_sphere *spheres, int n_spheres, const rt_vec3 *start,
-                              const rt_vec3 *normal, const rt_light *light, int n, float *dirs,
-                              float *brightness)
+static int debug_light_impl(const rt_sphere *spheres, int n_spheres, const rt_vec3 *start,
+                            const rt_vec3 *normal, const rt_light *light, int n, float *dirs,
+                            float *brightness, float *approx_dirs, int *approx_ok)
 {
     if (n <= 0 || n_spheres < 0 || !start || !normal || !light || !dirs || !brightness) return RT_ERR_INVALID;
     rt_scene sc;
@@ -1685,8 +1693,33 @@ extern "C" int rt_debug_light(const rt_sphere *spheres, int n_spheres, const rt_
     RT_HIP(hipMemcpy(dtab.p, tab.data(), sizeof(float4) * tab.size(), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(dstart.p, start, sizeof(float) * 3 * n, hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(dnormal.p, normal, sizeof(float) * 3 * n, hipMemcpyHostToDevice));
-    RT_HIP(rt_dev_launch_dbg_light(&fc, dtab.p, dstart.p, dnormal.p, 0, n, ddirs.p, dbright.p, nullptr));
+    DevBuf<float> dadirs;
+    DevBuf<int> daok;
+    if (approx_dirs && ((rc = dadirs.alloc(30 * (size_t)n)) || (rc = daok.alloc(10 * (size_t)n)))) return rc;
+    RT_HIP(rt_dev_launch_dbg_light(&fc, dtab.p, dstart.p, dnormal.p, 0, n, ddirs.p, dbright.p, approx_dirs ? dadirs.p : nullptr,
+                                   approx_dirs ? daok.p : nullptr, nullptr));
     RT_HIP(hipMemcpy(dirs, ddirs.p, sizeof(float) * 30 * n, hipMemcpyDeviceToHost));
     RT_HIP(hipMemcpy(brightness, dbright.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (approx_dirs) {
+        RT_HIP(hipMemcpy(approx_dirs, dadirs.p, sizeof(float) * 30 * n, hipMemcpyDeviceToHost));
+        RT_HIP(hipMemcpy(approx_ok, daok.p, sizeof(int) * 10 * n, hipMemcpyDeviceToHost));
+    }
     return RT_OK;
+}
+
+extern "C" int rt_debug_light(const rt_sphere *spheres, int n_spheres, const rt_vec3 *start,
+                              const rt_vec3 *normal, const rt_light *light, int n, float *dirs,
+                              float *brightness)
+{
+    return debug_light_impl(spheres, n_spheres, start, normal, light, n, dirs, brightness, nullptr, nullptr);
+}
+
+// The exact sample directions next to the pre-pass's approximate ones (frame kernel: setup_approx / direction_approx)
+// and the pre-pass's guard flags, for the error bound RT_PRE_DELTA (tests only).
+extern "C" int rt_debug_light_prepass(const rt_vec3 *start, const rt_light *light, int n, float *dirs, float *approx_dirs, int *approx_ok)
+{
+    if (!approx_dirs || !approx_ok || n <= 0) return RT_ERR_INVALID;
+    std::vector<rt_vec3> normal((size_t)n, rt_vec3{0.f, 1.f, 0.f});
+    std::vector<float> bright((size_t)n);
+    return debug_light_impl(nullptr, 0, start, normal.data(), light, n, dirs, bright.data(), approx_dirs, approx_ok);
 }

@@ -42,7 +42,8 @@ __global__ void rt_dbg_intersect(const float4 *tab, const float *rays, int n, in
 // castLightRay for n independent (start, normal) pairs against the whole table
 // (brute force, no culling): the 10 sample directions and the returned brightness.
 __global__ void rt_dbg_light(const RtFrameConsts fc, const float4 *tab, const float *starts,
-                             const float *normals, int light_index, int n, float *dirs, float *bright)
+                             const float *normals, int light_index, int n, float *dirs, float *bright,
+                             float *adirs, int *aok)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
@@ -53,6 +54,22 @@ __global__ void rt_dbg_light(const RtFrameConsts fc, const float4 *tab, const fl
     const bool force_slow = (fc.flags & RT_FLAG_FORCE_SLOW) != 0;
     const RtLightDev L = ax->lights[light_index];
     ShadowChain<false> chain;
+    if (adirs) {   // the pre-pass's approximate directions, formed exactly as the frame kernel forms them
+        V3 t{L.px - start.x, L.py - start.y, L.pz - start.z};
+        const float inv = __builtin_amdgcn_rsqf(__builtin_fmaf(t.x, t.x, __builtin_fmaf(t.y, t.y, t.z * t.z)));
+        t.x *= inv; t.y *= inv; t.z *= inv;
+        const bool lane_ok = chain.setup_approx(L, start, t);
+        for (int j = 0; j < RT_SHADOW_SAMPLES; ++j) {
+            bool ok;
+            const V3 d = chain.direction_approx(ax, L, j, ok);
+            if (live) {
+                adirs[30 * i + 3 * j + 0] = d.x;
+                adirs[30 * i + 3 * j + 1] = d.y;
+                adirs[30 * i + 3 * j + 2] = d.z;
+                aok[10 * i + j] = (lane_ok && ok) ? 1 : 0;
+            }
+        }
+    }
     chain.begin(V3{L.px, L.py, L.pz}, start);
     int unshadowed = 0;
     for (int j = 0; j < RT_SHADOW_SAMPLES; ++j) {
@@ -282,9 +299,9 @@ extern "C" hipError_t rt_dev_launch_dbg_intersect(const float4 *tab, const float
 
 extern "C" hipError_t rt_dev_launch_dbg_light(const RtFrameConsts *fc, const float4 *tab, const float *starts,
                                               const float *normals, int light_index, int n, float *dirs,
-                                              float *bright, hipStream_t stream)
+                                              float *bright, float *adirs, int *aok, hipStream_t stream)
 {
     hipLaunchKernelGGL(rt_dbg_light, dim3((n + 63) / 64), dim3(64), 0, stream, *fc, tab, starts, normals,
-                       light_index, n, dirs, bright);
+                       light_index, n, dirs, bright, adirs, aok);
     return hipGetLastError();
 }

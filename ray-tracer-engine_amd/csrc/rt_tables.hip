@@ -350,8 +350,10 @@ void rt_build_occluder_lists(const float4 *tab, int n, const float lpos_f[3], st
         hdr[si].kcap = (float)(kcap * 0.9999);
         for (const auto &kv : keep) ent.push_back(tab[kv.second]);
     }
-    ent.resize((ent.size() + 63) & ~(size_t)63, make_float4(0.f, 0.f, 0.f, 0.f));   // a wave may read a whole step past a list's end
-    if (ent.empty()) ent.resize(64, make_float4(0.f, 0.f, 0.f, 0.f));
+    // A wave reads whole steps of 64 entries from a list's offset on (build_list_cand): up to 63 entries past the end of
+    // the list -- for the last list, past the end of the array. Pad by a whole step (a first version rounded the TOTAL up
+    // to a multiple of 64, which pads nothing when it already is one: a read past the allocation, caught by the soak).
+    ent.resize(ent.size() + 64, make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
 // ---------------------------------------------------------------------------

@@ -163,6 +163,40 @@ def test_shortcuts_equal_the_long_forms(rt, gpu):
         assert out[2] > 0.995 * (1 << 27) * 0.8, out[2]      # the over-sampled seams and poles are rejected more often
 
 
+def test_prepass_directions_stay_within_their_error_bound(rt, gpu):
+    """The sample pre-pass of the frame kernel (rt_trace.inc: setup_approx / direction_approx / presure_test)
+    classifies shadow rays with APPROXIMATE directions and relies on |approximate - exact| < RT_PRE_DELTA = 1e-5
+    wherever its guards let a direction through. Measured here on the device for 200 000 starts x 10 samples per
+    light: starts in and around the scene for the three reference lights, and for random lights -- close ones, ones
+    along the axes (toL near +-z is where the frame's rotation axis is ill-conditioned: the guard must cut in) and
+    far ones. The largest deviation seen must stay below a third of the bound."""
+    lib = rt.load_library()
+    rng = np.random.default_rng(5)
+    n = 200000
+    fp = C.POINTER(C.c_float)
+    cases = [((20, 20, 20), 20.0), ((0, 20, -20), 20.0), ((0, 20, 0), 20.0), ((3, 4, 40), 5.0), ((0.5, -0.25, -30), 30.0),
+             ((12, 9, 11), 2.0), ((-40, 3, 5), 0.5), ((5, 5, 30), 20.0)]
+    worst = 0.0
+    used = 0
+    for (lpos, size) in cases:
+        pts = rng.uniform(-2.0, 12.0, size=(n, 3)).astype(np.float32)
+        starts = (rt.Vec3 * n).from_buffer_copy(pts.tobytes())
+        light = rt.Light(rt.Vec3(*lpos), size, 1, 1, 1)
+        d = np.zeros((n, 10, 3), dtype=np.float32)
+        a = np.zeros((n, 10, 3), dtype=np.float32)
+        ok = np.zeros((n, 10), dtype=np.int32)
+        assert lib.rt_debug_light_prepass(starts, C.byref(light), n, d.ctypes.data_as(fp), a.ctypes.data_as(fp),
+                                          ok.ctypes.data_as(C.POINTER(C.c_int))) == 0, lib.rt_last_error()
+        dev = np.linalg.norm(a.astype(np.float64) - d.astype(np.float64), axis=2)
+        dev = np.where(np.isfinite(dev), dev, np.inf)          # an exact NaN direction with the guard open would be a miss
+        m = ok.astype(bool)
+        used += int(m.sum())
+        if m.any():
+            worst = max(worst, float(dev[m].max()))
+    assert used > 0.5 * len(cases) * n * 10                    # the guards let most samples through
+    assert worst < 1.0e-5 / 3, worst
+
+
 # ---------------------------------------------------------------- frames vs golden
 @pytest.mark.parametrize("cull", [True, False])
 @pytest.mark.parametrize("name", sorted(GOLDEN_CASES))

@@ -68,3 +68,31 @@ def test_occluder_lists_contain_every_sphere_a_shadow_ray_hits(rt, oracle, n):
                 assert not missing, (n, li, si, j, missing)
                 checked += len(hit)
         assert checked > 100
+
+
+def test_whole_steps_read_from_any_list_stay_inside_the_entry_array(rt):
+    """The kernel reads an occluder list in whole steps of 64 entries from its offset on (build_list_cand), i.e. up to 63
+    entries past the list's end -- for the last list of a light, past the end of the entries themselves. The array must
+    be allocated for that (a first version rounded the total up to a multiple of 64, which pads nothing when the total
+    already is one or when the last list needs a second step: a read past the allocation that a soak run found as a
+    GPU page fault). Random scenes of the soak's kind, every list of every light."""
+    lib = rt.load_library()
+    rng = np.random.default_rng(3)
+    for trial in range(12):
+        n = int(rng.choice([64, 200, 700, 1500]))
+        ext = float(rng.choice([4.0, 10.0, 25.0]))
+        sph = (rt.Sphere * n)()
+        for i in range(n):
+            r = float(rng.choice([rng.uniform(0, 1), rng.uniform(0.9, 1.6), 0.03]))
+            lib.rt_sphere_init(C.byref(sph[i]), *[float(v) for v in rng.uniform(-0.1 * ext, ext, 3)], r)
+        light = rt.Light(rt.Vec3(*[float(v) for v in rng.uniform(-40, 40, 3)]), 10.0, 1, 1, 1)
+        counts, offsets = (C.c_int * n)(), (C.c_int * n)()
+        kcaps = (C.c_float * n)()
+        alloc = C.c_int()
+        assert lib.rt_debug_occluder_lists_ex(sph, n, C.byref(light), counts, kcaps, None, 0, offsets, C.byref(alloc)) == 0
+        c, o = np.array(counts[:]), np.array(offsets[:])
+        has = c > 0
+        if has.any():
+            need = int((o[has] + (c[has] + 63) // 64 * 64).max())
+            assert need <= alloc.value, (trial, n, need, alloc.value)
+        assert alloc.value >= 64
