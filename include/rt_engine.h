@@ -460,6 +460,8 @@ int rt_debug_shortcuts(int what, unsigned seed, long long n, unsigned long long 
 int rt_debug_occluder_lists(const rt_sphere *spheres, int n, const rt_light *light, int *counts, float *kcaps, int *members, int cap);
 /* ... plus every list's offset into the light's entry array (offsets[i], or NULL) and the number of entries that array is
  * allocated with (the kernel reads whole steps of 64 entries from a list's offset on)                                     */
+/* ... and as the DEVICE builds them (what a scene uses: one wave per sphere, members in list order); needs a GPU */
+int rt_debug_occluder_lists_device(const rt_sphere *spheres, int n, const rt_light *light, int *counts, float *kcaps, int *members, int cap);
 int rt_debug_occluder_lists_ex(const rt_sphere *spheres, int n, const rt_light *light, int *counts, float *kcaps, int *members, int cap,
                                int *offsets, int *entries_allocated);
 

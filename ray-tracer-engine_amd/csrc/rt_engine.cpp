@@ -234,7 +234,7 @@ struct rt_scene {
 
 static const int kMaxSpheresLds = (160 * 1024 - RT_WAVES_PER_WG * (RT_LIST_CAP * 20 + 16 * 4 + 64 * 4 + RT_BOX_CAP * 4)) / 16;
 static const int kMaxSpheres = 1 << 22;
-static const int kMaxSpheresOccluders = 16384;   // the per-sphere occluder lists are an O(n^2) host build per light
+static const int kMaxSpheresOccluders = 8192;    // the per-sphere occluder lists take n * 128 entries (2 KiB per sphere) per light
 
 extern "C" rt_scene *rt_scene_create(void)
 {
@@ -498,12 +498,13 @@ static int rt_scene_prepare_lights(rt_scene *s, hipStream_t stream)
     return RT_OK;
 }
 
-// Per-light occluder lists (rt_tables.hip): which spheres a shadow ray from each sphere's surface can hit at all.
-// Host build, O(n^2) per light, when the list or a light's position changes.
+// Per-light occluder lists (rt_tables.hip): which spheres a shadow ray from each sphere's surface can hit at all. Built
+// on the DEVICE (one wave per sphere and light, from the list-order table that is already there) when the list or a
+// light's position changes; the host waits for the build (rare, ~0.1 ms) so that frames on any stream may follow.
 static int rt_scene_prepare_occluders(rt_scene *s, hipStream_t stream)
 {
     const int n = s->n_spheres;
-    bool want = n >= 64 && n <= kMaxSpheresOccluders && s->h_prev.size() == (size_t)n;
+    bool want = n >= 64 && n <= kMaxSpheresOccluders && s->h_prev.size() == (size_t)n && s->d_spheres;
 #ifdef RT_TUNING
     if (s->tune_no_light_columns) want = false;
 #endif
@@ -520,32 +521,28 @@ static int rt_scene_prepare_occluders(rt_scene *s, hipStream_t stream)
     if (same) return RT_OK;
     int rc = rt_scene_quiesce(s);   // frames in flight may be reading the old lists
     if (rc != RT_OK) return rc;
-    std::vector<std::vector<RtCandHdr>> hdr((size_t)s->n_lights);
-    std::vector<std::vector<float4>> ent((size_t)s->n_lights);
-    size_t bytes = sizeof(RtCandHdr) * (size_t)n * (size_t)s->n_lights;
-    for (int i = 0; i < s->n_lights; ++i) {
-        const float p[3] = {s->lights[i].pos.x, s->lights[i].pos.y, s->lights[i].pos.z};
-        memcpy(s->cand_pos[i], p, sizeof p);
-        rt_build_occluder_lists(s->h_prev.data(), n, p, hdr[i], ent[i]);
-        s->cand_ent_off[i] = bytes;
-        bytes += sizeof(float4) * ent[i].size();
-    }
+    const size_t hdr_bytes = sizeof(RtCandHdr) * (size_t)n, ent_bytes = sizeof(float4) * (size_t)n * RT_CAND_CAP;
+    const size_t bytes = (hdr_bytes + ent_bytes) * (size_t)s->n_lights;
     if (bytes > s->cap_cand) {
         if (s->d_cand) RT_HIP(hipFree(s->d_cand));
         s->d_cand = nullptr;
         s->cap_cand = 0;
         RT_HIP(hipMalloc((void **)&s->d_cand, bytes));
         s->cap_cand = bytes;
+        // a wave reads whole steps of 64 from a slot and masks what lies past the count: let that be zeros, once
+        RT_HIP(hipMemsetAsync(s->d_cand, 0, bytes, stream));
     }
-    std::vector<char> h(bytes);
+    if (s->stage_busy) RT_HIP(hipStreamWaitEvent(stream, s->stage_done, 0));   // the table the build reads may still be on its way
     for (int i = 0; i < s->n_lights; ++i) {
-        memcpy(h.data() + sizeof(RtCandHdr) * (size_t)n * (size_t)i, hdr[i].data(), sizeof(RtCandHdr) * (size_t)n);
-        memcpy(h.data() + s->cand_ent_off[i], ent[i].data(), sizeof(float4) * ent[i].size());
+        const float p[3] = {s->lights[i].pos.x, s->lights[i].pos.y, s->lights[i].pos.z};
+        memcpy(s->cand_pos[i], p, sizeof p);
+        s->cand_ent_off[i] = hdr_bytes * (size_t)s->n_lights + ent_bytes * (size_t)i;
+        RT_HIP(rt_occluder_lists_launch(s->d_spheres, n, p, reinterpret_cast<RtCandHdr *>(s->d_cand + hdr_bytes * (size_t)i),
+                                        reinterpret_cast<float4 *>(s->d_cand + s->cand_ent_off[i]), stream));
         s->cand_valid[i] = true;
     }
     for (int i = s->n_lights; i < RT_MAX_LIGHTS; ++i) s->cand_valid[i] = false;
-    RT_HIP(hipMemcpyAsync(s->d_cand, h.data(), bytes, hipMemcpyHostToDevice, stream));
-    RT_HIP(hipStreamSynchronize(stream));   // rare (scene or light change): `h` goes out of scope
+    RT_HIP(hipStreamSynchronize(stream));
     s->cand_gen = s->sphere_gen;
     s->cand_n_lights = s->n_lights;
     s->epoch++;
@@ -1630,6 +1627,38 @@ extern "C" int rt_debug_occluder_lists_ex(const rt_sphere *spheres, int n, const
         counts[i] = hdr[(size_t)i].count;
         kcaps[i] = hdr[(size_t)i].kcap;
         if (offsets) offsets[i] = hdr[(size_t)i].offset;
+        for (int k = 0; k < cap; ++k) members[(size_t)i * cap + k] = -1;
+        for (int k = 0; k < hdr[(size_t)i].count && k < cap; ++k) {
+            const float4 e = ent[(size_t)hdr[(size_t)i].offset + k];
+            for (int j = 0; j < n; ++j)
+                if (memcmp(&tab[(size_t)j], &e, sizeof e) == 0) { members[(size_t)i * cap + k] = j; break; }
+        }
+    }
+    return RT_OK;
+}
+
+// The same lists as the DEVICE builds them (rt_occluder_lists_launch: what the scene uses), downloaded: counts, kcaps and
+// the first `cap` members of every list as list positions (device order = table order).
+extern "C" int rt_debug_occluder_lists_device(const rt_sphere *spheres, int n, const rt_light *light, int *counts, float *kcaps, int *members, int cap)
+{
+    if (n <= 0 || !spheres || !light || !counts || !kcaps || (cap > 0 && !members)) return RT_ERR_INVALID;
+    std::vector<float4> tab((size_t)n);
+    pack_spheres(spheres, n, tab.data());
+    DevBuf<float4> dtab, dent;
+    DevBuf<RtCandHdr> dhdr;
+    int rc;
+    if ((rc = dtab.alloc((size_t)n)) || (rc = dent.alloc((size_t)n * RT_CAND_CAP)) || (rc = dhdr.alloc((size_t)n))) return rc;
+    RT_HIP(hipMemcpy(dtab.p, tab.data(), sizeof(float4) * (size_t)n, hipMemcpyHostToDevice));
+    RT_HIP(hipMemset(dent.p, 0, sizeof(float4) * (size_t)n * RT_CAND_CAP));
+    const float p[3] = {light->pos.x, light->pos.y, light->pos.z};
+    RT_HIP(rt_occluder_lists_launch(dtab.p, n, p, dhdr.p, dent.p, nullptr));
+    std::vector<RtCandHdr> hdr((size_t)n);
+    std::vector<float4> ent((size_t)n * RT_CAND_CAP);
+    RT_HIP(hipMemcpy(hdr.data(), dhdr.p, sizeof(RtCandHdr) * (size_t)n, hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(ent.data(), dent.p, sizeof(float4) * ent.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+        counts[i] = hdr[(size_t)i].count;
+        kcaps[i] = hdr[(size_t)i].kcap;
         for (int k = 0; k < cap; ++k) members[(size_t)i * cap + k] = -1;
         for (int k = 0; k < hdr[(size_t)i].count && k < cap; ++k) {
             const float4 e = ent[(size_t)hdr[(size_t)i].offset + k];

@@ -380,3 +380,22 @@ def test_fuzz_occluder_shortcuts(rt, gpu, seed):
                        *[float(v) for v in rng.uniform(0.2, 1.0, 3)]))
     cam = _cam(rt, tuple(rng.uniform(0, 10, 3) + np.array([0, 2, 6])), float(rng.uniform(150, 210)), float(rng.uniform(-35, 5)))
     Scn(rt, sph, lights=lights, cam=cam).check(96, 64, tiles=(8, 16))
+
+
+@pytest.mark.parametrize("cam_up", [0.9, -0.9])
+def test_camera_between_concentric_spheres(rt, gpu, cam_up):
+    """The camera sits between two CONCENTRIC spheres, two lights and seventy small occluders in the shell with it.
+    intersect() returns the near root even when it is negative (kernel.cu:1335 keeps the smallest t of any sign), so
+    every pixel's closest hit is the OUTER sphere, behind the camera -- the inner one is never a closest hit, which is
+    what lets the kernel form its shading groups (and pick their occluder lists) by the centre of the closest sphere."""
+    rng = np.random.default_rng(91)
+    c = np.array([20.0, 15.0, 25.0])
+    sph = [tuple(c) + (1.0,), tuple(c) + (3.0,)]
+    while len(sph) < 72:
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        sph.append(tuple(c + d * float(rng.uniform(1.3, 2.7))) + (float(rng.uniform(0.05, 0.2)),))
+    lights = [(tuple(c + np.array([1.8, 1.5, 0.5])), 1.0, 1.0, 0.9, 0.8), (tuple(c + np.array([-1.2, -1.9, 0.8])), 3.0, 0.3, 0.6, 1.0)]
+    cam = _cam(rt, tuple(c + np.array([0.0, cam_up, 2.2])), 180.0, -22.0 * np.sign(cam_up))
+    cnt = Scn(rt, sph, lights=lights, cam=cam).check(128, 96, tiles=(8, 16))
+    assert cnt["hit_pixels"] == 128 * 96

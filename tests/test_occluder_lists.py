@@ -96,3 +96,37 @@ def test_whole_steps_read_from_any_list_stay_inside_the_entry_array(rt):
             need = int((o[has] + (c[has] + 63) // 64 * 64).max())
             assert need <= alloc.value, (trial, n, need, alloc.value)
         assert alloc.value >= 64
+
+
+@pytest.mark.gpu
+def test_device_built_lists_equal_the_host_built_ones(rt, gpu):
+    """The scene builds its occluder lists on the DEVICE (one wave per sphere and light); the host builder above is the
+    same binary64 member test in a plain loop. Same members (as sets: the device keeps table order, the host sorts), same
+    counts, same slope caps -- for the BASELINE scenes and the reference's lights, plus a scene with a non-finite sphere
+    (no lists at all) and a light inside the scene (no lists for spheres whose beams have no bound)."""
+    lib = rt.load_library()
+    cap = 128
+    for n in (256, 1024):
+        sph = rt.generate_spheres(n, 1)
+        lights = list(rt.default_lights()) + [rt.Light(rt.Vec3(5, 5, 5), 3.0, 1, 1, 1)]
+        for light in lights:
+            ch, cd = (C.c_int * n)(), (C.c_int * n)()
+            kh, kd = (C.c_float * n)(), (C.c_float * n)()
+            mh, md = (C.c_int * (n * cap))(), (C.c_int * (n * cap))()
+            assert lib.rt_debug_occluder_lists(sph, n, C.byref(light), ch, kh, mh, cap) == 0
+            assert lib.rt_debug_occluder_lists_device(sph, n, C.byref(light), cd, kd, md, cap) == 0, lib.rt_last_error()
+            ch_, cd_ = np.array(ch[:]), np.array(cd[:])
+            assert np.array_equal(ch_, cd_)
+            has = ch_ >= 0
+            assert np.allclose(np.array(kh[:])[has], np.array(kd[:])[has], rtol=1e-6)
+            mh_, md_ = np.array(mh[:]).reshape(n, cap), np.array(md[:]).reshape(n, cap)
+            for i in np.nonzero(has)[0]:
+                assert set(mh_[i, :ch_[i]]) == set(md_[i, :cd_[i]]), i
+    sph = rt.generate_spheres(256, 1)
+    sph[17].orgin.x = float("nan")
+    ch, cd = (C.c_int * 256)(), (C.c_int * 256)()
+    kh = (C.c_float * 256)()
+    light = rt.default_lights()[0]
+    assert lib.rt_debug_occluder_lists(sph, 256, C.byref(light), ch, kh, None, 0) == 0
+    assert lib.rt_debug_occluder_lists_device(sph, 256, C.byref(light), cd, kh, None, 0) == 0
+    assert (np.array(ch[:]) == -1).all() and (np.array(cd[:]) == -1).all()
