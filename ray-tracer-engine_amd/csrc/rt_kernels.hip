@@ -255,6 +255,7 @@ extern "C" hipError_t rt_dev_trace_config(const RtFrameConsts *fc, int tile_w, i
                             (size_t)wpw * 16 * sizeof(float) +          // brightness table per wave
                             (size_t)wpw * 64 * sizeof(int) +            // marked blocks of a culling pass
                             (size_t)wpw * 16 * sizeof(double) +         // atan(k/8) per wave
+                            (size_t)wpw * 192 * sizeof(float) +         // texel colours per pixel
                             (feat == 2 ? (size_t)wpw * (RT_BOX_CAP + 128) * sizeof(int) : 0));
     const int th = 64 / tile_w;
     const int wgx = (tile_w <= 16 && wpw >= 2) ? 2 : 1;

@@ -3,6 +3,7 @@
 stamps). Read the SHARES, not the run time (stamps serialise the phases)."""
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 import rt_amd
 
@@ -17,6 +18,8 @@ a = ap.parse_args()
 rt = rt_amd.load()
 scene = rt.Scene.default(a.spheres)
 il = (a.interleave[0], a.interleave[1], 16) if a.interleave else None
+from _settle import settle
+settle(lambda: scene.render(a.width, a.height, cull=not a.no_cull, tile=a.tile, interleave=il), torch.cuda.synchronize)   # clocks up first
 out = scene.render(a.width, a.height, want_stats=True, profile=True, cull=not a.no_cull, tile=a.tile, interleave=il)
 torch.cuda.synchronize()
 st = out["stats"]
