@@ -460,6 +460,12 @@ int rt_debug_shortcuts(int what, unsigned seed, long long n, unsigned long long 
 int rt_debug_occluder_lists(const rt_sphere *spheres, int n, const rt_light *light, int *counts, float *kcaps, int *members, int cap);
 /* ... plus every list's offset into the light's entry array (offsets[i], or NULL) and the number of entries that array is
  * allocated with (the kernel reads whole steps of 64 entries from a list's offset on)                                     */
+/* The beam slope of every group of pixels on a sphere (what the frame kernel takes instead of bounding the sample spread
+ * per tile; -1: none), host builder and device builder (either pointer may be NULL; the device one needs a GPU), the
+ * same for one ball, and the spread s = sigma / (|l.pos| - frob) at ONE start with the 3x3 matrix it comes from */
+int rt_debug_sphere_beam_slopes(const rt_sphere *spheres, int n, const rt_light *light, float *host_kbeam, float *device_kbeam);
+double rt_debug_sphere_beam_slope(const double lpos[3], const double centre[3], double r0);
+double rt_debug_beam_sine(const double lpos[3], const double start[3], double *sigma, double *frob, double m9[9]);
 /* ... and as the DEVICE builds them (what a scene uses: one wave per sphere, members in list order); needs a GPU */
 int rt_debug_occluder_lists_device(const rt_sphere *spheres, int n, const rt_light *light, int *counts, float *kcaps, int *members, int cap);
 int rt_debug_occluder_lists_ex(const rt_sphere *spheres, int n, const rt_light *light, int *counts, float *kcaps, int *members, int cap,

@@ -207,6 +207,9 @@ def load_library():
         "rt_debug_shortcuts": (ci, [ci, C.c_uint, C.c_longlong, C.POINTER(C.c_ulonglong)]),
         "rt_debug_light_prepass": (ci, [C.POINTER(Vec3), C.POINTER(Light), ci, fp, fp, C.POINTER(ci)]),
         "rt_debug_occluder_lists": (ci, [C.POINTER(Sphere), ci, C.POINTER(Light), C.POINTER(ci), fp, C.POINTER(ci), ci]),
+        "rt_debug_sphere_beam_slopes": (ci, [C.POINTER(Sphere), ci, C.POINTER(Light), fp, fp]),
+        "rt_debug_sphere_beam_slope": (C.c_double, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double]),
+        "rt_debug_beam_sine": (C.c_double, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "rt_debug_occluder_lists_device": (ci, [C.POINTER(Sphere), ci, C.POINTER(Light), C.POINTER(ci), fp, C.POINTER(ci), ci]),
         "rt_debug_occluder_lists_ex": (ci, [C.POINTER(Sphere), ci, C.POINTER(Light), C.POINTER(ci), fp, C.POINTER(ci), ci,
                                             C.POINTER(ci), C.POINTER(ci)]),

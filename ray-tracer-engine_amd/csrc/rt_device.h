@@ -98,7 +98,8 @@ struct RtLightDev {
 struct RtCandHdr {      // one sphere's occluder list for one light (RtFrameAux::cand_hdr)
     int offset, count;  // entries [offset, offset + count) of the light's entry array; count < 0: no list
     float kcap;         // largest beam slope the list was built for
-    float pad_;
+    float kbeam;        // > 0: the beam slope of ANY group of pixels on this sphere for this light (rt_tables.hip:
+                        // rt_sphere_beam_slope) -- the kernel takes it instead of bounding the spread per tile; else -1
 };
 #define RT_CAND_CAP 128         // longest occluder list kept (= RT_LIST_CAP: what a wave's LDS list holds)
 

@@ -1637,6 +1637,42 @@ extern "C" int rt_debug_occluder_lists_ex(const rt_sphere *spheres, int n, const
     return RT_OK;
 }
 
+// The per-sphere beam slopes (RtCandHdr::kbeam; -1: none) as the host builder (host_kbeam, or NULL) and the device builder
+// (device_kbeam, or NULL: no GPU needed then) compute them, and the pieces of the bound for tests: the spread at ONE start.
+extern "C" int rt_debug_sphere_beam_slopes(const rt_sphere *spheres, int n, const rt_light *light, float *host_kbeam, float *device_kbeam)
+{
+    if (n <= 0 || !spheres || !light) return RT_ERR_INVALID;
+    std::vector<float4> tab((size_t)n);
+    pack_spheres(spheres, n, tab.data());
+    const float p[3] = {light->pos.x, light->pos.y, light->pos.z};
+    if (host_kbeam) {
+        std::vector<RtCandHdr> hdr;
+        std::vector<float4> ent;
+        rt_build_occluder_lists(tab.data(), n, p, hdr, ent);
+        for (int i = 0; i < n; ++i) host_kbeam[i] = hdr[(size_t)i].kbeam;
+    }
+    if (device_kbeam) {
+        DevBuf<float4> dtab, dent;
+        DevBuf<RtCandHdr> dhdr;
+        int rc;
+        if ((rc = dtab.alloc((size_t)n)) || (rc = dent.alloc((size_t)n * RT_CAND_CAP)) || (rc = dhdr.alloc((size_t)n))) return rc;
+        RT_HIP(hipMemcpy(dtab.p, tab.data(), sizeof(float4) * (size_t)n, hipMemcpyHostToDevice));
+        RT_HIP(rt_occluder_lists_launch(dtab.p, n, p, dhdr.p, dent.p, nullptr));
+        std::vector<RtCandHdr> hdr((size_t)n);
+        RT_HIP(hipMemcpy(hdr.data(), dhdr.p, sizeof(RtCandHdr) * (size_t)n, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) device_kbeam[i] = hdr[(size_t)i].kbeam;
+    }
+    return RT_OK;
+}
+extern "C" double rt_debug_sphere_beam_slope(const double lpos[3], const double centre[3], double r0)
+{
+    return rt_sphere_beam_slope(lpos, centre, r0);
+}
+extern "C" double rt_debug_beam_sine(const double lpos[3], const double start[3], double *sigma, double *frob, double m9[9])
+{
+    return rt_beam_sine_at_start(lpos, start, sigma, frob, m9);
+}
+
 // The same lists as the DEVICE builds them (rt_occluder_lists_launch: what the scene uses), downloaded: counts, kcaps and
 // the first `cap` members of every list as list positions (device order = table order).
 extern "C" int rt_debug_occluder_lists_device(const rt_sphere *spheres, int n, const rt_light *light, int *counts, float *kcaps, int *members, int cap)

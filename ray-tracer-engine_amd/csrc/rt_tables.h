@@ -19,6 +19,9 @@ void rt_build_occluder_lists(const float4 *tab, int n, const float lpos[3], std:
 // Slope of the beam the frame kernel gives a group of shadow rays that start at `start` (binary64 restatement of the
 // kernel's bound; NaN when it has none).
 double rt_light_beam_slope(const double lpos[3], const double start[3]);
+// ... and its supremum over every start in the ball B(c, r0) (the slope a group of pixels on that sphere uses); -1: none
+double rt_sphere_beam_slope(const double lpos[3], const double c[3], double r0);
+double rt_beam_sine_at_start(const double lpos[3], const double start[3], double *sigma, double *frob, double m9[9]);
 // The lists built on the device (one wave per sphere): hdr: n records, ent: n * RT_CAND_CAP entries (a slot per sphere).
 hipError_t rt_occluder_lists_launch(const float4 *tab, int n, const float lpos[3], RtCandHdr *hdr, float4 *ent, hipStream_t stream);
 void rt_build_eye_cones_host(const float4 *tab, int n, const float org[3], float4 *sorted, float4 *blocks, int *orig);

@@ -308,6 +308,151 @@ RT_HDI double light_beam_slope_hd(const double lpos[3], const double start[3])
 
 double rt_light_beam_slope(const double lpos[3], const double start[3]) { return light_beam_slope_hd(lpos, start); }
 
+// ---------------------------------------------------------------------------
+// The same bound once per SPHERE instead of once per tile and light: the supremum of the spread over every start in the
+// ball B(c, r0) around a sphere -- which the frame kernel then takes as its beam's slope for any group of pixels on that
+// sphere, without computing anything (the per-tile evaluation is a hundred instructions per lit light).
+//   The spread depends on the start only through t = normalise(l.pos - start): s(t) = sigma_max(M(t) E) / (|l.pos| -
+// ||M(t)||_F), M the (non-standard) rotation of kernel.cu:1267-1277 about (0,0,1) x t, E an orthonormal pair across u.
+// The directions t of all starts in the ball form the cone of half-angle theta = asin(r0 / |l.pos - c|) around
+// t_c = normalise(l.pos - c). s is sampled at 217 directions of that cone (the axis and rings of 6k points at
+// alpha = theta k/8, k = 1..8: every direction of the cone is within 0.091 theta of a sample) and a Lipschitz term covers
+// the rest: sigma_max and ||.||_F are 1-Lipschitz in the Frobenius norm and ||E||_2 = 1, so |ds| <= ||dM||_F (1/den +
+// sigma/den^2), and along the unit sphere, with t = (q cos phi, q sin phi, t_z): M00 = t_z + sin^2 phi,
+// M01 = M10 = -sin(2 phi)(1 - t_z)/2, M11 = t_z + cos^2 phi (1 - t_z), M02 = M20 = -t_x, M12 = -M21 = t_y, M22 = t_z, whose
+// derivatives along an arc ds (|d phi| <= ds/q, |d t_z| <= ds) give ||dM||_F <= (4/q + 3) ds (checked numerically in
+// tests/test_occluder_lists.py). sigma <= ||M||_F <= sqrt(6) everywhere (same test). Where the cone comes within 0.1 of
+// the pole q = 0 (the light within six degrees of +-z as seen from the sphere) the bound for ANY direction is taken:
+// sqrt(6) / (|l.pos| - sqrt(6)). Returns the slope as the kernel forms it from the spread (RT_SPREAD_MUL / _ADD: the
+// allowances for the chain's own float arithmetic), or -1 where there is no usable bound (the kernel then evaluates its
+// own, per tile).
+RT_HDI void light_frame_hd(const double lpos[3], double *Lout, double u[3], double e1[3], double e2[3])
+{
+    const double L = sqrt(lpos[0] * lpos[0] + lpos[1] * lpos[1] + lpos[2] * lpos[2]);
+    *Lout = L;
+    for (int i = 0; i < 3; ++i) u[i] = lpos[i] / L;
+    const int k = (fabs(u[0]) <= fabs(u[1]) && fabs(u[0]) <= fabs(u[2])) ? 0 : (fabs(u[1]) <= fabs(u[2]) ? 1 : 2);
+    for (int i = 0; i < 3; ++i) e1[i] = -u[k] * u[i] + (i == k ? 1.0 : 0.0);
+    const double l1 = sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    for (int i = 0; i < 3; ++i) e1[i] /= l1;
+    e2[0] = u[1] * e1[2] - u[2] * e1[1];
+    e2[1] = u[2] * e1[0] - u[0] * e1[2];
+    e2[2] = u[0] * e1[1] - u[1] * e1[0];
+}
+
+// s(t) for a unit t away from the pole; *fro = ||M(t)||_F, *sig = sigma_max(M(t) E)
+RT_HDI double beam_sine_hd(const double t[3], const double e1[3], const double e2[3], double L, double *sig, double *fro)
+{
+    const double c = t[2], q2 = t[0] * t[0] + t[1] * t[1], sn = sqrt(q2);
+    const double rq = 1.0 / sn, ax = -t[1] * rq, ay = t[0] * rq, omc = 1.0 - c;
+    const double M[3][3] = {{c + ax * ax, ax * ay * omc, -ay * sn}, {ax * ay * omc, c + ay * ay * omc, -ax * sn}, {-ay * sn, ax * sn, c}};
+    double p[3], q[3], frob2 = 0;
+    for (int i = 0; i < 3; ++i) {
+        p[i] = M[i][0] * e1[0] + M[i][1] * e1[1] + M[i][2] * e1[2];
+        q[i] = M[i][0] * e2[0] + M[i][1] * e2[1] + M[i][2] * e2[2];
+        frob2 += M[i][0] * M[i][0] + M[i][1] * M[i][1] + M[i][2] * M[i][2];
+    }
+    const double h11 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2], h22 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+    const double h12 = p[0] * q[0] + p[1] * q[1] + p[2] * q[2], hd = 0.5 * (h11 - h22);
+    *sig = sqrt(0.5 * (h11 + h22) + sqrt(hd * hd + h12 * h12));
+    *fro = sqrt(frob2);
+    return *sig / (L - *fro);
+}
+
+#define RT_CONE_SAMPLES 217   // 1 + 6 (1 + 2 + ... + 8)
+// the i-th sample direction of the cone of half-angle theta around tc (a1, a2: an orthonormal pair across tc)
+RT_HDI void cone_sample_hd(int i, const double tc[3], const double a1[3], const double a2[3], double theta, double t[3])
+{
+    int k = 0;
+    while (i >= 1 + 3 * k * (k + 1)) ++k;                   // ring k holds the indices 1 + 3k(k-1) .. 3k(k+1)
+    const double alpha = theta * (double)k / 8.0;
+    const double psi = k ? 6.283185307179586 * (double)(i - 1 - 3 * k * (k - 1)) / (double)(6 * k) : 0.0;
+    const double ca = cos(alpha), sa = sin(alpha), cp = cos(psi), sp = sin(psi);
+    for (int j = 0; j < 3; ++j) t[j] = ca * tc[j] + sa * (cp * a1[j] + sp * a2[j]);
+    const double l = sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+    for (int j = 0; j < 3; ++j) t[j] /= l;
+}
+
+struct ConeOfStarts {       // what every evaluation of one (sphere, light) pair shares
+    double L, e1[3], e2[3], tc[3], a1[3], a2[3], theta, qmin, den_min;
+    bool usable, polar;
+};
+RT_HDI ConeOfStarts cone_of_starts_hd(const double lpos[3], const double c[3], double r0)
+{
+    ConeOfStarts k;
+    double u[3];
+    light_frame_hd(lpos, &k.L, u, k.e1, k.e2);
+    const double w[3] = {lpos[0] - c[0], lpos[1] - c[1], lpos[2] - c[2]};
+    const double D = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    k.den_min = k.L - 2.46;                                  // ||M||_F <= sqrt(6) = 2.4495
+    k.usable = (k.L > 0) && fin_d(k.L + D + r0) && (r0 >= 0) && (D > 0) && (r0 <= 0.3 * D) && (k.den_min > 0.05 * k.L);
+    k.theta = 0; k.qmin = 0; k.polar = true;
+    for (int i = 0; i < 3; ++i) { k.tc[i] = 0; k.a1[i] = 0; k.a2[i] = 0; }
+    if (!k.usable) return k;
+    for (int i = 0; i < 3; ++i) k.tc[i] = w[i] / D;
+    k.theta = asin(r0 / D) * 1.001 + 2.0e-6;                // (+ the float chain's toL against the exact direction)
+    k.qmin = sqrt(k.tc[0] * k.tc[0] + k.tc[1] * k.tc[1]) - k.theta * 1.01;
+    k.polar = !(k.qmin >= 0.1);
+    // a1, a2 across tc
+    const int m = (fabs(k.tc[0]) <= fabs(k.tc[1]) && fabs(k.tc[0]) <= fabs(k.tc[2])) ? 0 : (fabs(k.tc[1]) <= fabs(k.tc[2]) ? 1 : 2);
+    for (int i = 0; i < 3; ++i) k.a1[i] = -k.tc[m] * k.tc[i] + (i == m ? 1.0 : 0.0);
+    const double l1 = sqrt(k.a1[0] * k.a1[0] + k.a1[1] * k.a1[1] + k.a1[2] * k.a1[2]);
+    for (int i = 0; i < 3; ++i) k.a1[i] /= l1;
+    k.a2[0] = k.tc[1] * k.a1[2] - k.tc[2] * k.a1[1];
+    k.a2[1] = k.tc[2] * k.a1[0] - k.tc[0] * k.a1[2];
+    k.a2[2] = k.tc[0] * k.a1[1] - k.tc[1] * k.a1[0];
+    return k;
+}
+// from the largest sampled s (or anything, for a polar cone) to the slope; -1: no bound
+RT_HDI double cone_slope_hd(const ConeOfStarts &k, double s_max_sampled)
+{
+    if (!k.usable) return -1.0;
+    double s_sup;
+    if (k.polar) {
+        s_sup = 2.46 / k.den_min;
+    } else {
+        if (!(s_max_sampled == s_max_sampled)) return -1.0;
+        const double G = (4.0 / k.qmin + 3.0) * 1.05 * (1.0 / k.den_min + 2.46 / (k.den_min * k.den_min));
+        s_sup = s_max_sampled + G * (0.12 * k.theta);
+    }
+    s_sup *= 1.00001;
+    if (!(s_sup < 0.45)) return -1.0;
+    const double snw = s_sup * (double)RT_SPREAD_MUL + (double)RT_SPREAD_ADD;
+    return snw / sqrt(fmax(1.0 - snw * snw, 0.05)) * 1.000001;
+}
+
+// s, sigma_max(M E), ||M||_F and M itself at t = normalise(l.pos - start): for the tests of the bound
+double rt_beam_sine_at_start(const double lpos[3], const double start[3], double *sigma, double *frob, double m9[9])
+{
+    double L, u[3], e1[3], e2[3];
+    light_frame_hd(lpos, &L, u, e1, e2);
+    double t[3] = {lpos[0] - start[0], lpos[1] - start[1], lpos[2] - start[2]};
+    const double tl = sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+    for (int i = 0; i < 3; ++i) t[i] /= tl;
+    if (m9) {
+        const double c = t[2], sn = sqrt(t[0] * t[0] + t[1] * t[1]), ax = -t[1] / sn, ay = t[0] / sn, omc = 1.0 - c;
+        const double M[9] = {c + ax * ax, ax * ay * omc, -ay * sn, ax * ay * omc, c + ay * ay * omc, -ax * sn, -ay * sn, ax * sn, c};
+        for (int i = 0; i < 9; ++i) m9[i] = M[i];
+    }
+    return beam_sine_hd(t, e1, e2, L, sigma, frob);
+}
+
+double rt_sphere_beam_slope(const double lpos[3], const double c[3], double r0)
+{
+    const ConeOfStarts k = cone_of_starts_hd(lpos, c, r0);
+    double smax = 0;
+    if (k.usable && !k.polar) {
+        for (int i = 0; i < RT_CONE_SAMPLES; ++i) {
+            double t[3], sig, fro;
+            cone_sample_hd(i, k.tc, k.a1, k.a2, k.theta, t);
+            const double s = beam_sine_hd(t, k.e1, k.e2, k.L, &sig, &fro);
+            if (!(s == s)) return -1.0;
+            smax = s > smax ? s : smax;
+        }
+    }
+    return cone_slope_hd(k, smax);
+}
+
 // the k-th of the 14 points of a sphere at which the slope is sampled: the six axis points, the eight diagonals
 RT_HDI void occluder_probe_dir(int k, double d[3])
 {
@@ -342,7 +487,7 @@ RT_HDI bool occluder_member_hd(float4 T, const double c[3], const double u[3], d
 
 void rt_build_occluder_lists(const float4 *tab, int n, const float lpos_f[3], std::vector<RtCandHdr> &hdr, std::vector<float4> &ent)
 {
-    hdr.assign((size_t)n, RtCandHdr{0, -1, 0.f, 0.f});
+    hdr.assign((size_t)n, RtCandHdr{0, -1, 0.f, -1.f});
     ent.clear();
     const double lpos[3] = {lpos_f[0], lpos_f[1], lpos_f[2]};
     const double L = std::sqrt(lpos[0] * lpos[0] + lpos[1] * lpos[1] + lpos[2] * lpos[2]);
@@ -363,8 +508,11 @@ void rt_build_occluder_lists(const float4 *tab, int n, const float lpos_f[3], st
                 if (!(kk == kk)) usable = false;
                 kmax = std::max(kmax, kk);
             }
-            if (!usable) continue;
-            const double kcap = kmax * 1.15 + 1.0e-4, r0 = R * 1.001 + 1.0e-3;
+            const double r0 = R * 1.001 + 1.0e-3;
+            const double kbeam = rt_sphere_beam_slope(lpos, c, r0);   // the slope the kernel will use for groups on this sphere
+            hdr[si].kbeam = kbeam > 0 ? (float)kbeam : -1.f;           // (-1: it forms its own, and checks it against kcap)
+            if (!usable && !(kbeam > 0)) continue;
+            const double kcap = kbeam > 0 ? (double)(float)kbeam * 1.001 : kmax * 1.15 + 1.0e-4;
             keep.clear();
             for (int ti = 0; ti < n; ++ti) {
                 double key;
@@ -395,8 +543,29 @@ __global__ __launch_bounds__(64) void rt_occluder_lists_kernel(const float4 *__r
     const double lpos[3] = {lx, ly, lz};
     const double L = sqrt(lpos[0] * lpos[0] + lpos[1] * lpos[1] + lpos[2] * lpos[2]);
     const float4 S = tab[si];
-    const double c[3] = {S.x, S.y, S.z}, R = sqrt((double)S.w);
-    bool usable = (L > 0) && fin_d(L) && table_entry_finite(S);
+    const double c[3] = {S.x, S.y, S.z}, R = sqrt((double)S.w), r0 = R * 1.001 + 1.0e-3;
+    bool fin_all = (L > 0) && fin_d(L);                 // every entry of the table finite (a non-finite one: no lists at all)
+    const bool s_fin = table_entry_finite(S);
+    // the slope of every group on this sphere: the cone of starts, its 217 sample directions four to a lane
+    const ConeOfStarts cone = cone_of_starts_hd(lpos, c, s_fin ? r0 : NAN);
+    double smax = 0;
+    bool s_nan = false;
+    if (cone.usable && !cone.polar) {
+        for (int i = lane; i < RT_CONE_SAMPLES; i += 64) {
+            double t[3], sig, fro;
+            cone_sample_hd(i, cone.tc, cone.a1, cone.a2, cone.theta, t);
+            const double s = beam_sine_hd(t, cone.e1, cone.e2, cone.L, &sig, &fro);
+            s_nan = s_nan || !(s == s);
+            smax = s > smax ? s : smax;
+        }
+        s_nan = __any(s_nan);
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(smax, off);
+            smax = (o > smax) ? o : smax;
+        }
+    }
+    const double kbeam = cone_slope_hd(cone, s_nan ? NAN : smax);
+    // without one: 1.15 x the largest slope the kernel's own bound yields at 14 points of the sphere (it checks)
     double k = 0;
     if (lane < 14) {
         double d[3];
@@ -404,19 +573,20 @@ __global__ __launch_bounds__(64) void rt_occluder_lists_kernel(const float4 *__r
         const double st[3] = {c[0] + R * d[0], c[1] + R * d[1], c[2] + R * d[2]};
         k = light_beam_slope_hd(lpos, st);
     }
-    usable = usable && !__any(k != k);
+    const bool probes_ok = !__any(k != k);
     for (int off = 32; off > 0; off >>= 1) {
         const double o = __shfl_xor(k, off);
         k = (o > k) ? o : k;
     }
-    const double kcap = k * 1.15 + 1.0e-4, r0 = R * 1.001 + 1.0e-3;
+    const bool usable = s_fin && (kbeam > 0 || probes_ok);
+    const double kcap = kbeam > 0 ? (double)(float)kbeam * 1.001 : k * 1.15 + 1.0e-4;
     const double u[3] = {lpos[0] / L, lpos[1] / L, lpos[2] / L};
     int count = 0;
     for (int base = 0; base < n; base += 64) {
         const int ti = base + lane;
         const float4 T = tab[ti < n ? ti : n - 1];
         const bool fin = table_entry_finite(T);
-        if (__any(ti < n && !fin)) usable = false;
+        if (__any(ti < n && !fin)) fin_all = false;
         double key;
         const bool keep = usable && ti < n && fin && occluder_member_hd(T, c, u, r0, kcap, &key);
         const unsigned long long m = __ballot(keep);
@@ -427,9 +597,9 @@ __global__ __launch_bounds__(64) void rt_occluder_lists_kernel(const float4 *__r
     if (lane == 0) {
         RtCandHdr h;
         h.offset = si * RT_CAND_CAP;
-        h.count = (usable && count <= RT_CAND_CAP) ? count : -1;
+        h.count = (fin_all && usable && count <= RT_CAND_CAP) ? count : -1;
         h.kcap = (float)(kcap * 0.9999);
-        h.pad_ = 0.f;
+        h.kbeam = (fin_all && kbeam > 0) ? (float)kbeam : -1.f;
         hdr[si] = h;
     }
 }

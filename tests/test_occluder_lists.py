@@ -119,6 +119,10 @@ def test_device_built_lists_equal_the_host_built_ones(rt, gpu):
             assert np.array_equal(ch_, cd_)
             has = ch_ >= 0
             assert np.allclose(np.array(kh[:])[has], np.array(kd[:])[has], rtol=1e-6)
+            bh, bd = (C.c_float * n)(), (C.c_float * n)()
+            assert lib.rt_debug_sphere_beam_slopes(sph, n, C.byref(light), bh, bd) == 0, lib.rt_last_error()
+            bh_, bd_ = np.array(bh[:]), np.array(bd[:])
+            assert np.array_equal(bh_ > 0, bd_ > 0) and np.allclose(bh_, bd_, rtol=1e-6)   # the slope of a group on each sphere
             mh_, md_ = np.array(mh[:]).reshape(n, cap), np.array(md[:]).reshape(n, cap)
             for i in np.nonzero(has)[0]:
                 assert set(mh_[i, :ch_[i]]) == set(md_[i, :cd_[i]]), i
@@ -130,3 +134,79 @@ def test_device_built_lists_equal_the_host_built_ones(rt, gpu):
     assert lib.rt_debug_occluder_lists(sph, 256, C.byref(light), ch, kh, None, 0) == 0
     assert lib.rt_debug_occluder_lists_device(sph, 256, C.byref(light), cd, kh, None, 0) == 0
     assert (np.array(ch[:]) == -1).all() and (np.array(cd[:]) == -1).all()
+
+
+def _beam_sine(lib, lpos, start, want_m=False):
+    sig, fro = C.c_double(), C.c_double()
+    m9 = (C.c_double * 9)()
+    s = lib.rt_debug_beam_sine((C.c_double * 3)(*lpos), (C.c_double * 3)(*start), C.byref(sig), C.byref(fro), m9)
+    return (s, sig.value, fro.value, np.array(m9[:]).reshape(3, 3)) if want_m else (s, sig.value, fro.value)
+
+
+def test_matrix_norm_and_lipschitz_constants_of_the_sphere_bound(rt):
+    """The three facts rt_sphere_beam_slope rests on, checked numerically: ||M(t)||_F^2 <= 6 and sigma_max(M E) <= ||M||_F for
+    every direction t, and M moves by at most (4/q + 3) ds in the Frobenius norm along an arc ds of the unit sphere
+    (q = the distance of t from the z axis)."""
+    lib = rt.load_library()
+    rng = np.random.default_rng(5)
+    lpos = np.array([30.0, 40.0, 20.0])
+    worst = 0.0
+    for it in range(4000):
+        t = rng.normal(size=3)
+        if it % 4 == 0:   # close to the poles, where everything is largest
+            t = np.array([rng.normal() * 0.05, rng.normal() * 0.05, rng.choice([-1.0, 1.0])])
+        t /= np.linalg.norm(t)
+        q = float(np.hypot(t[0], t[1]))
+        if q < 1e-3:
+            continue
+        s, sig, fro, M = _beam_sine(lib, lpos, lpos - 7.0 * t, want_m=True)
+        assert fro * fro <= 6.0 + 1e-9 and sig <= fro + 1e-12
+        # a neighbour at arc ds in a random tangent direction
+        d = rng.normal(size=3)
+        d -= d.dot(t) * t
+        d /= np.linalg.norm(d)
+        ds = 1e-6 * q
+        t2 = np.cos(ds) * t + np.sin(ds) * d
+        M2 = _beam_sine(lib, lpos, lpos - 7.0 * t2, want_m=True)[3]
+        ratio = np.linalg.norm(M2 - M) / ds / (4.0 / q + 3.0)
+        worst = max(worst, ratio)
+    assert worst <= 1.0, worst
+
+
+def test_sphere_beam_slope_bounds_every_start_of_the_ball(rt):
+    """kbeam of a ball >= the slope the spread at ANY start in that ball turns into (4 000 random starts per ball, surface
+    and interior; the kernel's own per-tile bound is that spread with its float allowances). Balls near and far from the
+    light, on and off the z axis (the pole of the rotation), tiny and huge; a ball too close to the light has none."""
+    lib = rt.load_library()
+    rng = np.random.default_rng(11)
+    mul, add = 1.002, 5.0e-5      # RT_SPREAD_MUL / RT_SPREAD_ADD
+    n_with = n_tight = 0
+    for case in range(120):
+        lpos = rng.uniform(-40, 40, 3) if case % 3 else np.array([rng.normal() * 0.5, rng.normal() * 0.5, rng.choice([-35.0, 35.0])])
+        c = rng.uniform(-5, 15, 3)
+        if case % 5 == 0:
+            c = lpos * rng.uniform(0.0, 0.8) + rng.normal(size=3) * 0.3     # along the light's own direction
+        r0 = float(rng.choice([0.03, 0.5, 1.6, 4.0]))
+        kb = lib.rt_debug_sphere_beam_slope((C.c_double * 3)(*lpos), (C.c_double * 3)(*c), r0)
+        D = np.linalg.norm(lpos - c)
+        if r0 > 0.3 * D or np.linalg.norm(lpos) - 2.46 <= 0.05 * np.linalg.norm(lpos):
+            assert kb == -1.0
+            continue
+        if kb < 0:
+            continue
+        n_with += 1
+        worst = 0.0
+        for _ in range(4000):
+            d = rng.normal(size=3)
+            d /= np.linalg.norm(d)
+            start = c + d * r0 * (1.0 if rng.random() < 0.7 else rng.random() ** (1 / 3))
+            s = _beam_sine(lib, lpos, start)[0]
+            snw = s * mul + add
+            worst = max(worst, snw / np.sqrt(max(1 - snw * snw, 0.05)))
+        assert worst <= kb, (case, worst, kb)
+        tc = (lpos - c) / D
+        qmin = np.hypot(tc[0], tc[1]) - np.arcsin(r0 / D) * 1.02   # the cone of toL against the rotation's pole: below 0.1 the
+        if qmin >= 0.3:                                            # bound for ANY direction is taken, and near it the Lipschitz
+            assert kb <= worst * 1.25 + 2e-3, (case, worst, kb)    # term is large; elsewhere the bound is not a vacuous one
+            n_tight += 1
+    assert n_with > 60 and n_tight > 30
