@@ -40,6 +40,7 @@ out = {"no_mesh": run(0, False)}
 for name, bits in (("all", 0), ("no_lights", 16), ("no_lights_no_leaf_walk", 16 + 2048), ("no_lights_no_triangle_tests", 16 + 1024),
                    ("no_sphere_shadow_tests", 1), ("no_sample_construction", 2), 
                    ("no_leaf_walk", 2048), ("no_triangle_tests", 1024), ("no_shadow_mesh_loop", 8192),
-                   ("no_shadow_triangle_tests", 16384), ("no_light_box_lists", 32768)):
+                   ("no_shadow_triangle_tests", 16384), ("no_light_box_lists", 32768),
+                   ("no_occluder_lists", 65536), ("beam_slope_per_tile_not_per_sphere", 524288)):
     out[name] = run(bits)
 print(json.dumps(out, indent=1))
