@@ -303,7 +303,8 @@ def test_spp4_in_kernel_and_progressive(rt, gpu):
     assert np.array_equal(_bits(rgba1), _bits(ref)) and np.array_equal(packed1, refp)
 
 
-def test_graph_replay_equals_direct_launch(rt, gpu):
+@pytest.mark.parametrize("passes", [4, -4])   # four samples in one kernel node / four progressive one-sample nodes
+def test_graph_replay_equals_direct_launch(rt, gpu, passes):
     import torch
     lib = rt.load_library()
     w, h, n = 96, 54, 256
@@ -314,7 +315,7 @@ def test_graph_replay_equals_direct_launch(rt, gpu):
     host = torch.zeros((h, w), dtype=torch.int32).pin_memory()
     stream = torch.cuda.Stream()
     fd = scene.frame_desc(w, h, pixels=pk.data_ptr(), rgba=acc.data_ptr())
-    gr = lib.rt_graph_capture(scene.handle, C.byref(fd), 4, host.data_ptr(), stream.cuda_stream)
+    gr = lib.rt_graph_capture(scene.handle, C.byref(fd), passes, host.data_ptr(), stream.cuda_stream)
     assert gr, lib.rt_last_error()
     for _ in range(3):                                   # replays are idempotent
         assert lib.rt_graph_launch(gr, stream.cuda_stream) == 0
@@ -690,13 +691,17 @@ def test_full_size_c2_and_c4(rt, gpu):
     host = torch.zeros((h, w), dtype=torch.int32).pin_memory()
     stream = torch.cuda.Stream()
     fd = scene.frame_desc(w, h, pixels=pk.data_ptr(), rgba=acc.data_ptr())
-    gr = lib.rt_graph_capture(scene.handle, C.byref(fd), 4, host.data_ptr(), stream.cuda_stream)
-    assert gr, lib.rt_last_error()
-    for _ in range(2):
-        assert lib.rt_graph_launch(gr, stream.cuda_stream) == 0
-    stream.synchronize()
-    assert np.array_equal(_bits(acc.cpu().numpy()), _bits(rgba4))
-    assert np.array_equal(host.numpy().view(np.uint32), packed4) and np.array_equal(pk.cpu().numpy().view(np.uint32), packed4)
+    for passes in (4, -4):   # one node with the sample loop inside / four progressive nodes
+        acc.zero_(); pk.zero_(); host.zero_()
+        gr = lib.rt_graph_capture(scene.handle, C.byref(fd), passes, host.data_ptr(), stream.cuda_stream)
+        assert gr, lib.rt_last_error()
+        for _ in range(2):
+            assert lib.rt_graph_launch(gr, stream.cuda_stream) == 0
+        stream.synchronize()
+        assert np.array_equal(_bits(acc.cpu().numpy()), _bits(rgba4)), passes
+        assert np.array_equal(host.numpy().view(np.uint32), packed4) and np.array_equal(pk.cpu().numpy().view(np.uint32), packed4)
+        if passes == 4:
+            lib.rt_graph_destroy(gr)
     for name, (_, _, _, _, y0, y1) in GOLDEN_SPP_CASES.items():
         g = np.load(os.path.join(GOLD, name + ".npz"))
         assert np.array_equal(_bits(rgba4[y0:y1]), _bits(g["acc"])), name

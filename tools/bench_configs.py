@@ -52,8 +52,8 @@ pk = torch.zeros((h, w), dtype=torch.int32, device="cuda")
 host = torch.zeros((h, w), dtype=torch.int32).pin_memory()
 stream = torch.cuda.Stream()
 fd = s1024.frame_desc(w, h, pixels=pk.data_ptr(), rgba=acc.data_ptr())
-for with_copy in (False, True):
-    g = lib.rt_graph_capture(s1024.handle, C.byref(fd), 4, host.data_ptr() if with_copy else None, stream.cuda_stream)
+for passes, with_copy in ((4, False), (4, True), (-4, False)):
+    g = lib.rt_graph_capture(s1024.handle, C.byref(fd), passes, host.data_ptr() if with_copy else None, stream.cuda_stream)
     assert g, lib.rt_last_error()
     settle(lambda: lib.rt_graph_launch(g, stream.cuda_stream), stream.synchronize, window=5)
     t0 = time.perf_counter()
@@ -62,8 +62,9 @@ for with_copy in (False, True):
         lib.rt_graph_launch(g, stream.cuda_stream)
     stream.synchronize()
     ms = (time.perf_counter() - t0) / n * 1e3
-    out["C4_4spp_hipgraph" + ("_with_d2h" if with_copy else "")] = {"ms": ms, "Mrays_per_s": 4 * w * h / ms / 1e3, "fps": 1e3 / ms}
-    if not with_copy:
+    out["C4_4spp_hipgraph" + ("_with_d2h" if with_copy else "") + ("_four_progressive_nodes" if passes < 0 else "")] = {
+        "ms": ms, "Mrays_per_s": 4 * w * h / ms / 1e3, "fps": 1e3 / ms}
+    if not with_copy and passes > 0:
         # the camera nudged before every replay (kernel.cu:1727): node parameters replaced in the instantiated
         # graph, the graph's eye-cone table rebuilt by its own build node -- no re-capture, no synchronisation
         cam = rt.default_camera()
