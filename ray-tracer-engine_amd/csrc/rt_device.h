@@ -65,7 +65,7 @@
                                // (Their work-counter builds get RT_MIN_WAVES_PER_SIMD.)
 #endif
 #ifndef RT_MIN_WAVES_MESH
-#define RT_MIN_WAVES_MESH 6      // one-sample kernels with the triangle-mesh branches: 76 of 80 registers, no spill (round 2: 89 at 5 waves)
+#define RT_MIN_WAVES_MESH 7      // one-sample kernels with the triangle-mesh branches: 71 of 72 registers, no vector spill, 24 scalars in lanes (6 waves: 12; the 4K mesh frame 1.04 -> 0.975 ms; round 2: 89 registers at 5 waves)
 #endif
 #ifndef RT_MIN_WAVES_MESH_MULTI
 #define RT_MIN_WAVES_MESH_MULTI 4 // ... with a sample loop or work counters on top: 128 registers, no spill
