@@ -258,8 +258,10 @@ void rt_build_light_columns(const float4 *tab, int n, const float u_f[3], float4
 // then only has to cull the members against its own, much thinner beam (rt_trace.inc: build_list_cand) instead of
 // walking the light's column blocks. Conservative by the same member test the kernel applies (beam_member_test) with
 // the ball of S (radius R_S 1.001 + 1e-3: the starts lie 1e-5 above the surface, give or take the rounding of the hit
-// point) as the ray origins; kcap = 1.15 x the largest slope the kernel's own bound yields at 14 points of S, and the
-// kernel checks its beam's slope against it before using the list.
+// point) as the ray origins; kcap = the slope every group on S uses (kbeam, rt_sphere_beam_slope below) plus 0.1 %, or,
+// for a sphere without one, 1.15 x the largest slope the kernel's own bound yields at 14 points of S; the kernel checks
+// its beam's slope against kcap before using the list. Built on the device (rt_occluder_lists_kernel); the host builder
+// is the same member test in a plain loop, for the tests.
 // ---------------------------------------------------------------------------
 RT_HDI bool fin_d(double x) { return x - x == 0.0; }
 
