@@ -13,5 +13,6 @@ print("walks", v[17], "no_penumbra", v[18], "penumbra lanes", v[19], "lit lanes 
 print("fraction of walked lights without any penumbra lane:", v[18] / v[17], " mean penumbra lanes per walk:", v[19] / v[17], " of lit lanes", v[20] / v[17])
 print("walked lights whose lit lanes are ALL fully shadowed:", v[21], " ALL fully lit:", v[22])
 print("shadow list length histogram (<=1,<=2,<=4,<=8,<=16,<=cap, all clear, full occluder):", v[8:16])
-print("pre-pass: walks that needed the exact chain:", v[23] >> 32, " samples evaluated exactly (wave level):", v[23] & 0xffffffff,
-      " = per such walk", (v[23] & 0xffffffff) / max(1, v[23] >> 32))
+need, walks_need, single = v[23] & 0xffffff, (v[23] >> 24) & 0xfffff, v[23] >> 44
+print("pre-pass: walks that needed the exact chain:", walks_need, " samples evaluated exactly (wave level):", need,
+      " = per such walk", need / max(1, walks_need), " walks whose every sample has ONE entry that all lit pixels hit for sure:", single)
